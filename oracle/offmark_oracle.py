@@ -1,0 +1,561 @@
+"""CPU oracle for the offmark DCT watermark hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module is a NumPy restatement of the reference's per-frame DCT embed/detect
+algorithm.  It is the checker for the HIP kernels; it is never the product path.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.  Nothing under ``video-fingerprinting_amd/`` imports it.
+
+PARITY STATUS
+-------------
+* Control flow / scalar semantics: PINNED.  ``tests/golden/*.npz`` were produced by
+  importing the reference's own, unmodified ``dct_encoder.py`` / ``dct_decoder.py`` /
+  ``shuffler.py`` / ``de_shuffler.py`` / ``grayscale.py`` / ``de_grayscale.py`` in the
+  build container (``tools/make_golden.py``); this oracle reproduces those vectors
+  bit for bit (``tests/test_oracle_golden.py``).
+* OpenCV arithmetic (``cv2.dct`` / ``cv2.idct`` / ``cv2.cvtColor``, opencv-python
+  4.6.0.66 per the reference's ``pdm.lock:31-32``): PARITY UNPINNED.  OpenCV is not
+  installed here or on the GPU box and the reference holds no expected outputs for
+  this path, so the three primitives below are restated from their
+  published definitions (orthonormal 2-D DCT-II/III; BT.601 "YUV" float conversion
+  with delta = 0.5) and were supplied to the reference code as a ``cv2`` stand-in when
+  the golden vectors were captured.  Independent f32 DCT implementations differ by
+  <= ~1e-4 on 0..255-scale data; tests state tolerances accordingly.
+
+Reference files restated (relative to /root/reference):
+  src/offmark/video/embedder.py:33-39      -> mark_frame
+  src/offmark/video/extractor.py:30-34     -> check_frame
+  src/offmark/embed/dct_encoder.py:10-102  -> DctEncoderOracle / luminance_mask / texture_mask / qim_embed
+  src/offmark/extract/dct_decoder.py:10-27 -> DctDecoderOracle / qim_read
+  src/offmark/generator/shuffler.py:15-25, grayscale.py:16-31        -> shuffle_generate / grayscale_generate
+  src/offmark/degenerator/de_shuffler.py:8-22, de_grayscale.py:8-23  -> deshuffle / degrayscale
+  tests/segment_mark_detect_hls.py:126-155 -> vote
+
+Two forms of every block routine are provided and must agree bit for bit:
+  *_loop : per-block Python loops, shaped like the reference (small cases only)
+  *_vec  : all blocks at once (used for 1080p cases and the CPU baseline)
+
+NumPy promotion
+---------------
+The reference pins numpy 1.23.3 (``pdm.lock:25-26``; ``api/requirements.txt`` pins
+1.24.3), i.e. *legacy* value-based promotion: ``np.float32 scalar (op) python scalar``
+yields float64.  This container runs numpy 2.2 (NEP 50: stays float32).  The only place
+on this path where the two differ is ``texture_mask`` (``dct_encoder.py:92-101``).
+Every such expression below is written with explicit casts and a ``promotion`` switch:
+``"legacy"`` (default; the reference as pinned) or ``"nep50"`` (what the reference code
+computes when imported here; used to pin the oracle against the golden vectors).
+"""
+from __future__ import annotations
+
+import math
+from collections import Counter
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+# --------------------------------------------------------------------------------------
+# Third-party primitives (stand-ins for cv2 -- see header)
+# --------------------------------------------------------------------------------------
+
+def _dct_matrix() -> np.ndarray:
+    d = np.zeros((8, 8), dtype=F64)
+    for k in range(8):
+        s = math.sqrt(1.0 / 8.0) if k == 0 else math.sqrt(2.0 / 8.0)
+        for n in range(8):
+            d[k, n] = s * math.cos((2 * n + 1) * k * math.pi / 16.0)
+    return d
+
+
+DCT_D = _dct_matrix()          # DCT_D[k, n], orthonormal DCT-II basis
+
+
+def _apply_last(x: np.ndarray, m: np.ndarray) -> np.ndarray:
+    """out[..., k] = sum_n x[..., n] * m[k, n], accumulated n-ascending in float64.
+
+    Written as explicit elementwise ops so that a batch of one block and a batch of
+    32 400 blocks perform the identical arithmetic (BLAS may not)."""
+    out = np.empty_like(x)
+    for k in range(8):
+        acc = x[..., 0] * m[k, 0]
+        for n in range(1, 8):
+            acc = acc + x[..., n] * m[k, n]
+        out[..., k] = acc
+    return out
+
+
+def dct8x8(blocks: np.ndarray) -> np.ndarray:
+    """Orthonormal 2-D DCT-II of (..., 8, 8) float32 blocks -> float32.
+
+    Stand-in for ``cv2.dct`` on an 8x8 CV_32F block (call sites dct_encoder.py:29,50,79;
+    dct_decoder.py:23,38,66).  Computed in float64 and rounded once to float32."""
+    x = np.asarray(blocks, dtype=F32).astype(F64)
+    t = _apply_last(x, DCT_D)                         # rows: along n (last axis)
+    t = np.swapaxes(_apply_last(np.swapaxes(t, -1, -2), DCT_D), -1, -2)   # columns
+    return t.astype(F32)
+
+
+def idct8x8(coeffs: np.ndarray) -> np.ndarray:
+    """Orthonormal 2-D inverse DCT (DCT-III).  Stand-in for ``cv2.idct`` (dct_encoder.py:37)."""
+    x = np.asarray(coeffs, dtype=F32).astype(F64)
+    dt = np.ascontiguousarray(DCT_D.T)
+    t = _apply_last(x, dt)
+    t = np.swapaxes(_apply_last(np.swapaxes(t, -1, -2), dt), -1, -2)
+    return t.astype(F32)
+
+
+# OpenCV float "YUV" constants (color_yuv: B2Y, G2Y, R2Y, B2U-style 0.492, R2V-style 0.877)
+_C_Y = (F32(0.114), F32(0.587), F32(0.299))
+_C_U = F32(0.492)
+_C_V = F32(0.877)
+_DELTA = F32(0.5)            # float images: delta = 0.5 (not 128)
+_I_B = F32(2.032)
+_I_GU = F32(-0.395)
+_I_GV = F32(-0.581)
+_I_R = F32(1.140)
+
+
+def bgr2yuv_f32(img: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(f32, COLOR_BGR2YUV)`` stand-in (embedder.py:34, extractor.py:31).
+
+    Channel 0 is treated as "B" whatever the caller put there (the reference feeds
+    rgb24 frames, frame_reader.py:47) -- indices, not colour names, matter."""
+    a = np.asarray(img, dtype=F32)
+    c0, c1, c2 = a[..., 0], a[..., 1], a[..., 2]
+    y = (c0 * _C_Y[0] + c1 * _C_Y[1]) + c2 * _C_Y[2]
+    u = (c0 - y) * _C_U + _DELTA
+    v = (c2 - y) * _C_V + _DELTA
+    return np.stack([y, u, v], axis=-1).astype(F32)
+
+
+def yuv2bgr_f32(img: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(f32, COLOR_YUV2BGR)`` stand-in (embedder.py:36)."""
+    a = np.asarray(img, dtype=F32)
+    y, u, v = a[..., 0], a[..., 1] - _DELTA, a[..., 2] - _DELTA
+    c0 = y + u * _I_B
+    c1 = (y + u * _I_GU) + v * _I_GV
+    c2 = y + v * _I_R
+    return np.stack([c0, c1, c2], axis=-1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# Block helpers
+# --------------------------------------------------------------------------------------
+
+def to_blocks(plane: np.ndarray) -> np.ndarray:
+    """(H, W) -> (H//8, W//8, 8, 8) copy of the top-left block-aligned region."""
+    h8, w8 = plane.shape[0] // 8, plane.shape[1] // 8
+    p = plane[: h8 * 8, : w8 * 8]
+    return np.ascontiguousarray(p.reshape(h8, 8, w8, 8).transpose(0, 2, 1, 3))
+
+
+def from_blocks(blocks: np.ndarray, plane: np.ndarray) -> None:
+    """Write (h8, w8, 8, 8) blocks back into the top-left region of ``plane`` in place."""
+    h8, w8 = blocks.shape[:2]
+    plane[: h8 * 8, : w8 * 8] = blocks.transpose(0, 2, 1, 3).reshape(h8 * 8, w8 * 8)
+
+
+def np_sum_f32_8x8(a: np.ndarray) -> np.ndarray:
+    """``np.sum`` of a contiguous 8x8 float32 block, for a batch (..., 8, 8).
+
+    NumPy's pairwise reduction on 64 contiguous float32 uses 8 running accumulators
+    r[j] += a[8*i + j] and combines them ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))."""
+    r = a[..., 0, :].astype(F32, copy=True)
+    for i in range(1, 8):
+        r = r + a[..., i, :]
+    return ((r[..., 0] + r[..., 1]) + (r[..., 2] + r[..., 3])) + \
+           ((r[..., 4] + r[..., 5]) + (r[..., 6] + r[..., 7]))
+
+
+# --------------------------------------------------------------------------------------
+# a3  luminance mask  (dct_encoder.py:41-67 == dct_decoder.py:29-55)
+# --------------------------------------------------------------------------------------
+L_MIN, L_MAX, F_MAX = 90, 255, 2
+
+
+def luminance_from_dc(dc: np.ndarray) -> tuple[np.ndarray, float]:
+    """dc: (h8, w8) float32 DC coefficients of the Y blocks.  Returns (mask f64, mean)."""
+    m = dc.astype(F64) / 8
+    mean = max(L_MIN, np.mean(m))
+    f_ref = 1 + (mean - L_MIN) * (F_MAX - 1) / (L_MAX - L_MIN)
+    out = np.ones_like(m)
+    hi = m > mean
+    out[hi] = 1 + (m[hi] - mean) / (L_MAX - mean) * (F_MAX - f_ref)
+    lo15 = (~hi) & (m < 15)
+    lo25 = (~hi) & (~lo15) & (m < 25)
+    out[lo15] = 1.25
+    out[lo25] = 1.125
+    return out, float(mean)
+
+
+def luminance_mask_loop(lum: np.ndarray) -> np.ndarray:
+    rows, cols = lum.shape[0] // 8, lum.shape[1] // 8
+    mask = np.zeros((rows, cols))
+    for i in range(rows):
+        for j in range(cols):
+            mask[i, j] = dct8x8(lum[i * 8:i * 8 + 8, j * 8:j * 8 + 8])[0, 0]
+    mask /= 8
+    mean = max(L_MIN, np.mean(mask))
+    f_ref = 1 + (mean - L_MIN) * (F_MAX - 1) / (L_MAX - L_MIN)
+    for i in range(rows):
+        for j in range(cols):
+            m = mask[i, j]
+            if m > mean:
+                mask[i, j] = 1 + (m - mean) / (L_MAX - mean) * (F_MAX - f_ref)
+            elif m < 15:
+                mask[i, j] = 1.25
+            elif m < 25:
+                mask[i, j] = 1.125
+            else:
+                mask[i, j] = 1
+    return mask
+
+
+def luminance_mask_vec(lum: np.ndarray, ycoef: np.ndarray | None = None) -> np.ndarray:
+    if ycoef is None:
+        ycoef = dct8x8(to_blocks(lum))
+    return luminance_from_dc(ycoef[..., 0, 0])[0]
+
+
+# --------------------------------------------------------------------------------------
+# a4  texture mask  (dct_encoder.py:70-102 == dct_decoder.py:57-89)
+# --------------------------------------------------------------------------------------
+_A1, _B1, _A2, _B2 = 2.3, 1.6, 1.4, 1.1
+
+
+def _ge(x32, const: float, promotion: str):
+    """np.float32 scalar >= python float under the chosen promotion rules."""
+    if promotion == "legacy":
+        return x32.astype(F64) >= const          # both promoted to float64
+    return x32 >= F32(const)                     # python float demoted to float32
+
+
+def _ramp(eh32, promotion: str):
+    """``1 + 1.25 * (eh - 290) / (1800 - 290)`` with eh a float32 scalar."""
+    if promotion == "legacy":
+        return 1 + 1.25 * (eh32.astype(F64) - 290) / (1800 - 290)
+    t = (eh32 - F32(290)).astype(F32)
+    t = (F32(1.25) * t).astype(F32)
+    t = (t / F32(1800 - 290)).astype(F32)
+    return (F32(1) + t).astype(F64)
+
+
+def texture_features(acoef: np.ndarray):
+    """From |DCT(Y block)| (..., 8, 8) float32: (dcl, eh, e) float32 as the reference forms them."""
+    a = acoef
+    dcl = ((((a[..., 0, 0] + a[..., 0, 1]) + a[..., 0, 2]) + a[..., 1, 0]) + a[..., 1, 1]) + a[..., 2, 0]
+    eh = np_sum_f32_8x8(a) - dcl
+    e = a[..., 3, 0]
+    for (p, q) in ((4, 0), (5, 0), (6, 0), (0, 3), (0, 4), (0, 5), (0, 6), (2, 1), (1, 2), (2, 2), (3, 3)):
+        e = e + a[..., p, q]
+    return dcl.astype(F32), eh.astype(F32), e.astype(F32)
+
+
+def texture_from_features(a00, dcl, eh, e, promotion: str = "legacy") -> np.ndarray:
+    """Vectorised decision tree of texture_mask.  All inputs float32 arrays of one shape."""
+    a00, dcl, eh, e = (np.asarray(x, dtype=F32) for x in (a00, dcl, eh, e))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        h = eh - e
+        l = dcl - a00
+        l_e = l / e
+        le_h = (l + e) / h
+        lpe = l + e
+        eph = e + h
+    gt4 = le_h > F32(4)          # python int 4: exact either way
+
+    def cond(a, b):
+        return (_ge(l_e, a, promotion) & _ge(le_h, b, promotion)) | \
+               (_ge(l_e, b, promotion) & _ge(le_h, a, promotion)) | gt4
+
+    step_val = np.where(lpe <= F32(400), 1.125, 1.25)
+    ramp = _ramp(eh, promotion)
+    out = np.ones(eh.shape, dtype=F64)
+    active = eh > F32(125)
+    big = active & (eh > F32(900))
+    small = active & ~big
+    c2 = cond(_A2, _B2)
+    c1 = cond(_A1, _B1)
+    out = np.where(big & c2, step_val, out)
+    out = np.where(big & ~c2, ramp, out)
+    out = np.where(small & c1, step_val, out)
+    out = np.where(small & ~c1 & (eph > F32(290)), ramp, out)
+    return out
+
+
+def texture_mask_loop(lum: np.ndarray, promotion: str = "legacy") -> np.ndarray:
+    rows, cols = lum.shape[0] // 8, lum.shape[1] // 8
+    mask = np.full((rows, cols), 1.0)
+    for i in range(rows):
+        for j in range(cols):
+            c = np.abs(dct8x8(lum[i * 8:i * 8 + 8, j * 8:j * 8 + 8]))
+            dcl = c[0][0] + c[0][1] + c[0][2] + c[1][0] + c[1][1] + c[2][0]
+            eh = F32(np.sum(c) - dcl)
+            if eh > 125:
+                e = c[3][0] + c[4][0] + c[5][0] + c[6][0] + \
+                    c[0][3] + c[0][4] + c[0][5] + c[0][6] + \
+                    c[2][1] + c[1][2] + c[2][2] + c[3][3]
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    h = F32(eh - e)
+                    l = F32(dcl - c[0][0])
+                    l_e, le_h = F32(l / e), F32(F32(l + e) / h)
+
+                def cond(a, b):
+                    return (_ge(l_e, a, promotion) and _ge(le_h, b, promotion)) or \
+                           (_ge(l_e, b, promotion) and _ge(le_h, a, promotion)) or le_h > 4
+
+                if eh > 900:
+                    if cond(_A2, _B2):
+                        mask[i, j] = 1.125 if F32(l + e) <= 400 else 1.25
+                    else:
+                        mask[i, j] = _ramp(eh, promotion)
+                else:
+                    if cond(_A1, _B1):
+                        mask[i, j] = 1.125 if F32(l + e) <= 400 else 1.25
+                    elif F32(e + h) > 290:
+                        mask[i, j] = _ramp(eh, promotion)
+    return mask
+
+
+def texture_mask_vec(lum: np.ndarray, ycoef: np.ndarray | None = None, promotion: str = "legacy") -> np.ndarray:
+    if ycoef is None:
+        ycoef = dct8x8(to_blocks(lum))
+    a = np.abs(ycoef)
+    dcl, eh, e = texture_features(a)
+    return texture_from_features(a[..., 0, 0], dcl, eh, e, promotion)
+
+
+# --------------------------------------------------------------------------------------
+# a5 / a7  QIM on coefficient [2][1] of the U blocks
+# --------------------------------------------------------------------------------------
+
+def qim_embed(c21: np.ndarray, step: np.ndarray, bits: np.ndarray) -> np.ndarray:
+    """dct_encoder.py:30-35.  c21 float32, step float64, bits 0/1 -> new c21 float32.
+
+    ``abs(c)/step2`` is float32/float64 -> float64 under both promotion regimes;
+    ``np.sign(0) == 0`` so a zero coefficient stays zero and a '1' bit is lost there."""
+    c = np.asarray(c21, dtype=F32)
+    step = np.asarray(step, dtype=F64)
+    step2 = step + step
+    q = np.floor(np.abs(c).astype(F64) / step2) * step2
+    q = np.where(np.asarray(bits) == 0, q, q + step)
+    return (np.sign(c).astype(F64) * q).astype(F32)
+
+
+def qim_read(c21: np.ndarray, step: np.ndarray) -> np.ndarray:
+    """dct_decoder.py:24: ``int(np.around(c/step) % 2 == 1)``."""
+    x = np.asarray(c21, dtype=F32).astype(F64) / np.asarray(step, dtype=F64)
+    return (np.around(x) % 2 == 1).astype(F64)
+
+
+class DctEncoderOracle:
+    """dct_encoder.py:4-39.  ``form`` = "vec" | "loop"."""
+
+    def __init__(self, key=None, alpha=20, form: str = "vec", promotion: str = "legacy"):
+        self.key, self.alpha, self.form, self.promotion = key, alpha, form, promotion
+        self.debug: dict = {}
+
+    def read_wm(self, wm):
+        self.wm = wm[0]
+
+    def wm_capacity(self, frame_shape):
+        row, col, _ = frame_shape
+        return (1, row * col // 64)
+
+    def luminance_mask(self, lum):
+        return luminance_mask_loop(lum) if self.form == "loop" else luminance_mask_vec(lum)
+
+    def texture_mask(self, lum):
+        if self.form == "loop":
+            return texture_mask_loop(lum, self.promotion)
+        return texture_mask_vec(lum, promotion=self.promotion)
+
+    def encode(self, yuv):
+        return self._encode_loop(yuv) if self.form == "loop" else self._encode_vec(yuv)
+
+    def _encode_loop(self, yuv):
+        channel = yuv[:, :, 1]
+        mask = self.texture_mask(yuv[:, :, 0]) * self.luminance_mask(yuv[:, :, 0])
+        rows, cols = channel.shape[0] // 8, channel.shape[1] // 8
+        pre = np.zeros((rows, cols), F32)
+        post = np.zeros((rows, cols), F32)
+        c = 0
+        for i in range(rows):
+            for j in range(cols):
+                blk = channel[i * 8:i * 8 + 8, j * 8:j * 8 + 8]
+                coeffs = dct8x8(blk)
+                pre[i, j] = coeffs[2, 1]
+                step = self.alpha * mask[i][j]
+                coeffs[2, 1] = qim_embed(coeffs[2, 1], step, self.wm[c])
+                post[i, j] = coeffs[2, 1]
+                channel[i * 8:i * 8 + 8, j * 8:j * 8 + 8] = idct8x8(coeffs)
+                c += 1
+        self.debug = dict(mask=mask, c21_pre=pre, c21_post=post)
+        return yuv
+
+    def _encode_vec(self, yuv):
+        ycoef = dct8x8(to_blocks(yuv[:, :, 0]))
+        lum = luminance_mask_vec(None, ycoef)
+        tex = texture_mask_vec(None, ycoef, self.promotion)
+        mask = tex * lum
+        rows, cols = mask.shape
+        ucoef = dct8x8(to_blocks(yuv[:, :, 1]))
+        bits = np.asarray(self.wm)[: rows * cols].reshape(rows, cols)
+        pre = ucoef[..., 2, 1].copy()
+        post = qim_embed(pre, self.alpha * mask, bits)
+        ucoef[..., 2, 1] = post
+        from_blocks(idct8x8(ucoef), yuv[:, :, 1])
+        self.debug = dict(mask=mask, lum=lum, tex=tex, c21_pre=pre, c21_post=post, ydc=ycoef[..., 0, 0])
+        return yuv
+
+
+class DctDecoderOracle:
+    """dct_decoder.py:4-27."""
+
+    def __init__(self, key=None, alpha=20, form: str = "vec", promotion: str = "legacy"):
+        self.key, self.alpha, self.form, self.promotion = key, alpha, form, promotion
+        self.debug: dict = {}
+
+    def decode(self, yuv):
+        n = yuv.shape[0] * yuv.shape[1] // 8 // 8
+        wm = np.zeros(n)
+        rows, cols = yuv.shape[0] // 8, yuv.shape[1] // 8
+        if self.form == "loop":
+            mask = texture_mask_loop(yuv[:, :, 0], self.promotion) * luminance_mask_loop(yuv[:, :, 0])
+            c = 0
+            c21 = np.zeros((rows, cols), F32)
+            for i in range(rows):
+                for j in range(cols):
+                    step = self.alpha * mask[i][j]
+                    coeffs = dct8x8(yuv[i * 8:i * 8 + 8, j * 8:j * 8 + 8, 1])
+                    c21[i, j] = coeffs[2, 1]
+                    wm[c] = int(np.around(coeffs[2][1] / step) % 2 == 1)
+                    c += 1
+            self.debug = dict(mask=mask, c21=c21)
+        else:
+            ycoef = dct8x8(to_blocks(yuv[:, :, 0]))
+            lum = luminance_mask_vec(None, ycoef)
+            tex = texture_mask_vec(None, ycoef, self.promotion)
+            mask = tex * lum
+            c21 = dct8x8(to_blocks(yuv[:, :, 1]))[..., 2, 1]
+            wm[: rows * cols] = qim_read(c21, self.alpha * mask).reshape(-1)
+            self.debug = dict(mask=mask, lum=lum, tex=tex, c21=c21, ydc=ycoef[..., 0, 0])
+        return np.array(wm).reshape(1, -1)
+
+
+# --------------------------------------------------------------------------------------
+# a1 / a6  frame wrappers (video/embedder.py:33-39, video/extractor.py:30-34)
+# --------------------------------------------------------------------------------------
+
+def mark_frame(frame_u8: np.ndarray, encoder) -> np.ndarray:
+    yuv = bgr2yuv_f32(frame_u8.astype(F32))
+    yuv = encoder.encode(yuv)
+    rgb = yuv2bgr_f32(yuv)
+    rgb = np.clip(rgb, a_min=0, a_max=255)
+    return np.around(rgb).astype(np.uint8)
+
+
+def check_frame(frame_u8: np.ndarray, decoder, degenerator=None):
+    yuv = bgr2yuv_f32(frame_u8.astype(F32))
+    bits = decoder.decode(yuv)
+    return bits if degenerator is None else degenerator.degenerate(bits)
+
+
+# --------------------------------------------------------------------------------------
+# a8 / a9  payload codecs (generator/*.py, degenerator/*.py)
+# --------------------------------------------------------------------------------------
+
+def shuffle_generate(payload: np.ndarray, capacity, key) -> np.ndarray:
+    """generator/shuffler.py:15-25: key-seeded in-place shuffle of a copy, tiled to capacity."""
+    total = int(np.prod(np.array(capacity)))
+    p = np.copy(payload)
+    reps = int(math.ceil(total / int(np.prod(np.array(p.shape)))))
+    np.random.RandomState(key).shuffle(p)
+    return np.tile(p.reshape(-1), reps)[:total].reshape(capacity)
+
+
+def grayscale_generate(image: np.ndarray, capacity, key) -> np.ndarray:
+    """generator/grayscale.py:16-31: threshold at 127, flatten, shuffle, tile."""
+    total = int(np.prod(np.array(capacity)))
+    p = (image > 127).astype(np.uint8).flatten()
+    reps = int(math.ceil(total / p.size))
+    np.random.RandomState(key).shuffle(p)
+    return np.tile(p, reps)[:total].reshape(capacity)
+
+
+def payload_permutation(length: int, key) -> np.ndarray:
+    idx = np.arange(length)
+    np.random.RandomState(key).shuffle(idx)
+    return idx
+
+
+def deshuffle(wm_bits: np.ndarray, length: int, key) -> np.ndarray:
+    """degenerator/de_shuffler.py:14-22 (mean of every L-th bit, un-permute, mid-range threshold)."""
+    bits = np.asarray(wm_bits).flatten()
+    p = np.zeros(shape=length)
+    for i in range(length):
+        p[i] = bits[i::length].mean()
+    p[payload_permutation(length, key)] = p.copy()
+    thr = 0.5 * (np.max(p) + np.min(p))
+    return (p > thr).astype(np.uint8)
+
+
+def degrayscale(wm_bits: np.ndarray, shape, key) -> np.ndarray:
+    """degenerator/de_grayscale.py:15-23."""
+    length = int(np.prod(np.array(shape)))
+    return (deshuffle(wm_bits, length, key) * 255).astype(np.uint8).reshape(shape)
+
+
+class DeShufflerOracle:
+    def __init__(self, key=None):
+        self.key = key
+
+    def set_shape(self, payload_shape):
+        self.length = int(np.prod(np.array(payload_shape)))
+        return self
+
+    def degenerate(self, wm):
+        return deshuffle(wm, self.length, self.key)
+
+
+# --------------------------------------------------------------------------------------
+# a10  cross-frame vote (tests/segment_mark_detect_hls.py:126-155)
+# --------------------------------------------------------------------------------------
+
+def vote(patterns) -> tuple[np.ndarray | None, float | None]:
+    """Most common whole pattern over frames and its frequency (Counter, first-seen wins ties)."""
+    patterns = [np.asarray(p) for p in patterns]
+    if not patterns:
+        return None, None
+    strings = ["".join(map(str, p)) for p in patterns]
+    best, count = Counter(strings).most_common(1)[0]
+    return np.array([int(b) for b in best]), count / len(patterns)
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic frames (SURVEY.md 8d recipe) -- shared by tests and bench
+# --------------------------------------------------------------------------------------
+
+def synthetic_frame(h: int, w: int, seed: int) -> np.ndarray:
+    """Deterministic u8 (h, w, 3) test frame: smooth base + per-128x128-tile noise of
+    sigma in {0,2,8,24} + a brightness offset in {-60,-20,20,60} chosen by seed."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    gh, gw = max(2, h // 16 + 1), max(2, w // 16 + 1)
+    grid = rng.uniform(0, 255, size=(gh, gw, 3))
+    ys = np.linspace(0, gh - 1, h)
+    xs = np.linspace(0, gw - 1, w)
+    y0 = np.minimum(ys.astype(int), gh - 2)
+    x0 = np.minimum(xs.astype(int), gw - 2)
+    fy = (ys - y0)[:, None, None]
+    fx = (xs - x0)[None, :, None]
+    g00 = grid[y0][:, x0]
+    g01 = grid[y0][:, x0 + 1]
+    g10 = grid[y0 + 1][:, x0]
+    g11 = grid[y0 + 1][:, x0 + 1]
+    base = (g00 * (1 - fx) + g01 * fx) * (1 - fy) + (g10 * (1 - fx) + g11 * fx) * fy
+    sig = np.array([0.0, 2.0, 8.0, 24.0])
+    ty, tx = (h + 127) // 128, (w + 127) // 128
+    tile_sigma = sig[(np.arange(ty)[:, None] * 3 + np.arange(tx)[None, :] + seed) % 4]
+    sigma = np.kron(tile_sigma, np.ones((128, 128)))[:h, :w, None]
+    noise = rng.standard_normal(size=(h, w, 3)) * sigma
+    offset = (-60.0, -20.0, 20.0, 60.0)[seed % 4]
+    return np.around(np.clip(base + noise + offset, 0, 255)).astype(np.uint8)

@@ -1,0 +1,139 @@
+"""Pins oracle/offmark_oracle.py against vectors captured from the reference's own modules
+(tools/make_golden.py).  CPU only.  Bit-exact in ``promotion="nep50"`` mode, which is how the
+reference code evaluates under the numpy 2.x that generated the vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import offmark_oracle as orc
+from conftest import GOLDEN, golden_cases
+
+SMALL = [c for c in golden_cases() if "240x320" not in c and "qr" not in c]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def make_wm(g):
+    cap = (1, g["frame"].shape[0] * g["frame"].shape[1] // 64)
+    if bool(g["image_payload"]):
+        return orc.grayscale_generate(g["payload"], cap, int(g["key"]))
+    return orc.shuffle_generate(g["payload"], cap, int(g["key"]))
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_wm_generation_matches_reference(case):
+    g = load(case)
+    assert np.array_equal(make_wm(g), g["wm"])
+    L = int(np.prod(g["payload"].shape))
+    assert np.array_equal(orc.payload_permutation(L, int(g["key"])), g["perm"])
+
+
+@pytest.mark.parametrize("form", ["vec", "loop"])
+@pytest.mark.parametrize("case", SMALL)
+def test_masks_and_marked_frame_bit_exact(case, form):
+    g = load(case)
+    frame = g["frame"]
+    enc = orc.DctEncoderOracle(alpha=float(g["alpha"]) if g["alpha"] % 1 else int(g["alpha"]),
+                               form=form, promotion="nep50")
+    enc.read_wm(g["wm"])
+    yuv = orc.bgr2yuv_f32(frame.astype(np.float32))
+    assert np.array_equal(enc.luminance_mask(yuv[:, :, 0]), g["lum_mask"])
+    assert np.array_equal(enc.texture_mask(yuv[:, :, 0]), g["tex_mask"])
+    if "yuv_in" in g.files:
+        assert np.array_equal(yuv, g["yuv_in"])
+        assert np.array_equal(enc.encode(yuv.copy()), g["yuv_out"])
+    marked = orc.mark_frame(frame, enc)
+    assert np.array_equal(marked, g["marked"])
+
+
+@pytest.mark.parametrize("form", ["vec", "loop"])
+@pytest.mark.parametrize("case", SMALL)
+def test_decode_and_degenerate_bit_exact(case, form):
+    g = load(case)
+    dec = orc.DctDecoderOracle(alpha=int(g["alpha"]), form=form, promotion="nep50")
+    raw = orc.check_frame(g["marked"], dec)
+    assert raw.dtype == np.float64 and raw.shape == g["raw_bits"].shape
+    assert np.array_equal(raw, g["raw_bits"])
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if bool(g["image_payload"]):
+                out = orc.degrayscale(raw, g["payload"].shape, int(g["key"]))
+            else:
+                out = orc.deshuffle(raw, int(np.prod(g["payload"].shape)), int(g["key"]))
+    assert np.array_equal(out, g["degenerated"])
+
+
+@pytest.mark.parametrize("case", ["syn_240x320_L8_k0_a20", "frame63_crop_qr_k0_a20"])
+def test_larger_cases_vectorised(case):
+    g = load(case)
+    enc = orc.DctEncoderOracle(alpha=int(g["alpha"]), promotion="nep50")
+    enc.read_wm(g["wm"])
+    assert np.array_equal(orc.mark_frame(g["frame"], enc), g["marked"])
+    assert np.array_equal(enc.debug["lum"], g["lum_mask"])
+    assert np.array_equal(enc.debug["tex"], g["tex_mask"])
+    dec = orc.DctDecoderOracle(alpha=int(g["alpha"]), promotion="nep50")
+    raw = orc.check_frame(g["marked"], dec)
+    assert np.array_equal(raw, g["raw_bits"])
+    if bool(g["image_payload"]):
+        out = orc.degrayscale(raw, g["payload"].shape, int(g["key"]))
+        assert np.array_equal(out, g["degenerated"])
+        assert np.array_equal(out, (g["payload"] > 127).astype(np.uint8) * 255)
+    else:
+        out = orc.deshuffle(raw, g["payload"].size, int(g["key"]))
+        assert np.array_equal(out, g["degenerated"]) and np.array_equal(out, g["payload"])
+
+
+def test_payload_codecs_match_reference_numpy_only_modules():
+    g = np.load(os.path.join(GOLDEN, "payload_codecs.npz"))
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files})
+    assert len(tags) == 18
+    for t in tags:
+        key = int(t.split("_")[0][1:])
+        p, wm, noisy, back = (g[t + s] for s in ("_payload", "_wm", "_noisy", "_back"))
+        assert np.array_equal(orc.shuffle_generate(p, wm.shape, key), wm)
+        assert np.array_equal(orc.deshuffle(noisy, p.size, key), back)
+
+
+def test_known_permutation_key0_len8():
+    # positions take source indices [6 2 1 7 3 0 5 4]
+    assert orc.payload_permutation(8, 0).tolist() == [6, 2, 1, 7, 3, 0, 5, 4]
+    wm = orc.shuffle_generate(np.array([0, 1, 1, 0, 0, 1, 0, 1]), (1, 16), 0)
+    assert wm.tolist() == [[0, 1, 1, 1, 0, 0, 1, 0] * 2]
+
+
+def test_np_sum_emulation_matches_numpy():
+    rng = np.random.default_rng(0)
+    a = np.abs(rng.normal(0, 50, size=(2000, 8, 8))).astype(np.float32)
+    mine = orc.np_sum_f32_8x8(a)
+    ref = np.array([np.sum(b) for b in a], dtype=np.float32)
+    assert np.array_equal(mine, ref)
+
+
+def test_legacy_and_nep50_promotion_agree_to_rounding():
+    frame = orc.synthetic_frame(240, 320, 1001)
+    y = orc.bgr2yuv_f32(frame.astype(np.float32))[:, :, 0]
+    a = orc.texture_mask_vec(y, promotion="legacy")
+    b = orc.texture_mask_vec(y, promotion="nep50")
+    assert np.max(np.abs(a - b)) < 5e-7
+    assert len(np.unique(b)) > 3      # the ramp branch is exercised
+
+
+def test_dct_is_orthonormal_and_dc_is_sum_over_8():
+    rng = np.random.default_rng(1)
+    b = rng.uniform(0, 255, size=(50, 8, 8)).astype(np.float32)
+    c = orc.dct8x8(b)
+    assert np.allclose(c[:, 0, 0], b.sum(axis=(1, 2)) / 8, rtol=1e-6)
+    assert np.allclose(orc.idct8x8(c), b, atol=1e-3)
+    assert np.allclose((c.astype(np.float64) ** 2).sum(), (b.astype(np.float64) ** 2).sum(), rtol=1e-6)
+
+
+def test_vote_is_counter_mode():
+    pats = [np.array([0, 1]), np.array([1, 1]), np.array([0, 1])]
+    best, freq = orc.vote(pats)
+    assert best.tolist() == [0, 1] and abs(freq - 2 / 3) < 1e-12
+    assert orc.vote([]) == (None, None)

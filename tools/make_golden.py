@@ -1,0 +1,127 @@
+"""Generate tests/golden/*.npz by running the reference's own, unmodified modules.
+
+Run in the build container only (needs /root/reference):  python tools/make_golden.py
+
+* numpy-only reference modules (shuffler, grayscale, de_shuffler, de_grayscale) are imported
+  and run as they are -> fully pinned vectors.
+* dct_encoder / dct_decoder / video.embedder import ``cv2``; tools/cv2_standin supplies
+  dct / idct / cvtColor from the oracle primitives (OpenCV arithmetic itself unpinned).
+The reference's text is never copied: only inputs and outputs are stored.
+The container's numpy is 2.x, so the captured texture-mask values follow NEP 50 promotion
+(``promotion="nep50"`` in the oracle).
+"""
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "cv2_standin"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, "/root/reference/src")
+
+# video/embedder.py imports only cv2/numpy/logging; frame_reader/writer need ffmpeg -> not imported.
+import cv2  # noqa: E402  (the stand-in)
+import offmark_oracle as orc  # noqa: E402
+from offmark.degenerator.de_grayscale import DeGrayScale  # noqa: E402
+from offmark.degenerator.de_shuffler import DeShuffler  # noqa: E402
+from offmark.embed.dct_encoder import DctEncoder  # noqa: E402
+from offmark.extract.dct_decoder import DctDecoder  # noqa: E402
+from offmark.generator.grayscale import GrayScale  # noqa: E402
+from offmark.generator.shuffler import Shuffler  # noqa: E402
+from offmark.video.embedder import Embedder  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+logging.disable(logging.CRITICAL)
+
+
+def run_case(name, frame, payload, key, alpha, image_payload=False, store_yuv=False):
+    h, w, _ = frame.shape
+    enc = DctEncoder(alpha=alpha)
+    dec = DctDecoder(alpha=alpha)
+    cap = enc.wm_capacity((h, w, 3))
+    if image_payload:
+        gen, deg = GrayScale(key=key), DeGrayScale(key=key)
+    else:
+        gen, deg = Shuffler(key=key), DeShuffler(key=key)
+    wm = gen.generate_wm(payload, cap)
+    enc.read_wm(wm)
+    deg.set_shape(payload.shape)
+
+    yuv_in = cv2.cvtColor(frame.astype(np.float32), cv2.COLOR_BGR2YUV)
+    lum = enc.luminance_mask(yuv_in[:, :, 0])
+    tex = enc.texture_mask(yuv_in[:, :, 0])
+    yuv_out = enc.encode(yuv_in.copy())
+    marked = Embedder(None, enc, None)._Embedder__mark_frame(frame)       # embedder.py:33-39
+    # extractor.py:30-34 (its private method only logs; same three calls)
+    yuv_rx = cv2.cvtColor(marked.astype(np.float32), cv2.COLOR_BGR2YUV)
+    raw_bits = dec.decode(yuv_rx)
+    out = deg.degenerate(raw_bits)
+    raw_bits_clean = dec.decode(yuv_out.copy())        # decode straight from the f32 encoder output
+    d = dict(frame=frame, payload=np.asarray(payload), key=np.int64(key), alpha=np.float64(alpha),
+             image_payload=np.bool_(image_payload), wm=wm, lum_mask=lum, tex_mask=tex,
+             marked=marked, raw_bits=raw_bits, raw_bits_clean=raw_bits_clean, degenerated=out,
+             perm=deg.payload_idx)
+    if store_yuv:
+        d.update(yuv_in=yuv_in, yuv_out=yuv_out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    ok = np.array_equal(np.asarray(out).reshape(-1) // (255 if image_payload else 1),
+                        (np.asarray(payload).reshape(-1) > 127).astype(np.uint8) if image_payload
+                        else np.asarray(payload).reshape(-1))
+    print(f"{name:28s} {h}x{w} L={np.asarray(payload).size:4d} key={key} alpha={alpha} "
+          f"raw_ber={np.mean(raw_bits.reshape(-1)[:wm.size] != wm.reshape(-1)):.4f} payload_ok={ok}")
+
+
+def main():
+    P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    P5 = np.array([1, 0, 0, 1, 1])
+    run_case("syn_16x24_L8_k0_a20", orc.synthetic_frame(16, 24, 1), P8, 0, 20, store_yuv=True)
+    run_case("syn_64x96_L8_k0_a20", orc.synthetic_frame(64, 96, 2), P8, 0, 20, store_yuv=True)
+    run_case("syn_64x96_L5_k7_a10", orc.synthetic_frame(64, 96, 3), P5, 7, 10)
+    run_case("syn_240x320_L8_k0_a20", orc.synthetic_frame(240, 320, 1001), P8, 0, 20)
+    run_case("syn_30x44_L8_k0_a20", orc.synthetic_frame(30, 44, 5), P8, 0, 20, store_yuv=True)
+    big = orc.synthetic_frame(1080, 1920, 2000)
+    for n, (y, x) in enumerate([(0, 0), (128, 256), (512, 1024), (952, 1792)]):
+        run_case(f"syn1080_crop{n}_L8_k0_a20", np.ascontiguousarray(big[y:y + 128, x:x + 128]), P8, 0, 20)
+    # natural image shipped with the reference's tests (data file, decoded with Pillow)
+    from PIL import Image
+    nat = np.asarray(Image.open("/root/reference/tests/media/imgs/frame63.jpeg").convert("RGB"))
+    for n, (y, x) in enumerate([(300, 600), (700, 1200)]):
+        run_case(f"frame63_crop{n}_L8_k0_a20", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0, 20)
+    qr = np.asarray(Image.open("/root/reference/tests/media/wms/qr.jpeg").convert("L"))
+    run_case("frame63_crop_qr_k0_a20", np.ascontiguousarray(nat[256:256 + 256, 512:512 + 384]), qr, 0, 20,
+             image_payload=True)
+    # edge cases
+    run_case("edge_black_64x64", np.zeros((64, 64, 3), np.uint8), P8, 0, 20)
+    run_case("edge_white_64x64", np.full((64, 64, 3), 255, np.uint8), P8, 0, 20)
+    run_case("edge_gray_64x64", np.full((64, 64, 3), 128, np.uint8), P8, 0, 20)
+    run_case("edge_const_payload_64x96", orc.synthetic_frame(64, 96, 9), np.ones(8, dtype=np.int64), 0, 20)
+    # payload codecs alone (numpy-only reference modules, no stand-in involved)
+    rows = {}
+    for key in (0, 7, None):
+        for L in (5, 8, 13):
+            rs = np.random.RandomState(100 + L)
+            p = rs.randint(0, 2, size=L)
+            for cap in ((1, 300), (1, 32400), (1, 37)):
+                tag = f"k{key}_L{L}_c{cap[1]}"
+                if key is None:
+                    continue  # unseeded -> not reproducible
+                wm = Shuffler(key=key).generate_wm(p, cap)
+                noisy = wm.astype(np.float64).copy()
+                flip = rs.rand(noisy.size) < 0.2
+                noisy.reshape(-1)[flip] = 1 - noisy.reshape(-1)[flip]
+                back = DeShuffler(key=key).set_shape(p.shape).degenerate(noisy)
+                rows[tag + "_payload"] = p
+                rows[tag + "_wm"] = wm
+                rows[tag + "_noisy"] = noisy
+                rows[tag + "_back"] = back
+    np.savez_compressed(os.path.join(OUT, "payload_codecs.npz"), **rows)
+    print("payload_codecs", len(rows) // 4, "cases")
+
+
+if __name__ == "__main__":
+    main()
