@@ -1,0 +1,120 @@
+/* offmark_hip.h -- C ABI of the MI355X (gfx950) DCT frame-watermark engine.
+ *
+ * The reference (vikasdimaniya/video-fingerprinting, "offmark") is pure Python and has no FFI
+ * of its own; each entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  The Python package `offmark` in this repository
+ * binds these symbols with ctypes (video-fingerprinting_amd/offmark/_hip.py); INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer marked "device" is HBM memory owned by the caller (e.g. torch tensors);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is only
+ *     ENQUEUED on it: no allocation, no host synchronisation, no internal threads, so every
+ *     call except ofmk_stage_times_ms() may be captured into a hipGraph;
+ *   - return value 0 = OK, negative = error (OFMK_E_*); ofmk_last_error() gives the text for
+ *     the calling thread; nothing throws across this boundary;
+ *   - frames are interleaved 8-bit, 3 channels, row-major [n][H][W][3] exactly as
+ *     FileDecoder.read() delivers them (src/offmark/video/frame_reader.py:53-64).  Channel 0
+ *     is treated as "B" by the colour transform, as the reference does
+ *     (src/offmark/video/embedder.py:34).
+ *   - one watermark bit per 8x8 pixel block, raster order, N = H*W/64 entries per frame of
+ *     which the first (H/8)*(W/8) are used (src/offmark/embed/dct_encoder.py:13-16,25-26).
+ */
+#ifndef OFFMARK_HIP_H
+#define OFFMARK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFMK_ABI_VERSION 1
+
+#define OFMK_OK            0
+#define OFMK_E_ARG        -1   /* null pointer / non-positive size / H or W < 8 */
+#define OFMK_E_WORKSPACE  -2   /* workspace smaller than ofmk_workspace_bytes(1, H, W) */
+#define OFMK_E_HIP        -3   /* a HIP call failed; text in ofmk_last_error() */
+
+int ofmk_version(void);
+const char *ofmk_last_error(void);
+
+/* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
+ * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to
+ * what fits (bigger chunk = fewer launches; smaller chunk = the second pass over a chunk is
+ * served from the 256 MiB Infinity Cache). */
+size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W);
+
+/* ---- embed: replaces Embedder.__mark_frame + DctEncoder.encode for a batch of frames ------
+ * src/offmark/video/embedder.py:33-39, src/offmark/embed/dct_encoder.py:18-39.
+ *   in, out   device u8 [n][H][W][3]; out may alias in (in-place)
+ *   wm        device u8 [n_wm][N] of 0/1, N = H*W/64 (DctEncoder.read_wm keeps row 0 of the
+ *             generator's (1,N) array; n_wm > 1 lets segments carry different payloads)
+ *   wm_row    device int32 [n] giving the wm row of each frame, or NULL = row 0 for all
+ *   alpha     DctEncoder(alpha=20)
+ *   chunk_frames  frames per internal chunk, 0 = as many as the workspace holds            */
+int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
+                    const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
+                    int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- detect: replaces Extractor.__check_frame + DctDecoder.decode + the bits[i::L] sums ----
+ * src/offmark/video/extractor.py:30-34, src/offmark/extract/dct_decoder.py:10-27,
+ * src/offmark/degenerator/de_shuffler.py:17-18.
+ *   counts    device int32 [n][L]: number of 1 bits among raw_bits[i::L] (host finishes
+ *             DeShuffler.degenerate: mean, un-permute, mid-range threshold)
+ *   bits      device u8 [n][N] raw per-block bits (DctDecoder.decode's array), or NULL     */
+int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha,
+                     int32_t *counts, uint8_t *bits,
+                     int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- embed then detect the produced frames, chunk by chunk (mark + verify) ---------------
+ * The shape of tests/mark_video_to_hls.py:356-389 (verify every marked copy).  Same results as
+ * ofmk_embed_rgb8 followed by ofmk_detect_rgb8 on `out`; the detect pass of a chunk runs while
+ * the chunk is still cache resident. */
+int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
+                           const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
+                           int L, int32_t *counts, uint8_t *bits,
+                           int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- plugin-level entry points on float32 YUV frames --------------------------------------
+ * DctEncoder.encode(yuv) (dct_encoder.py:18-39; mutates channel 1 in place) and
+ * DctDecoder.decode(yuv) (dct_decoder.py:10-27).  yuv: device f32 [n][H][W][3].            */
+int ofmk_encode_yuv32f(float *yuv, int n, int H, int W,
+                       const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+int ofmk_decode_yuv32f(const float *yuv, int n, int H, int W, int L, double alpha,
+                       int32_t *counts, uint8_t *bits,
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- parity / debug planes for ONE frame (any pointer may be NULL) -----------------------
+ * DctEncoder.luminance_mask / texture_mask (dct_encoder.py:41-102) and the [2][1] coefficient
+ * before and after quantisation (dct_encoder.py:29-35).  All planes are [H/8][W/8].
+ *   src_is_yuv32f = 0: frame is u8 [H][W][3];  1: frame is f32 YUV [H][W][3]
+ *   wm may be NULL (then c21_post is not produced)                                          */
+int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double alpha,
+                      const uint8_t *wm,
+                      float *y_dc, double *lum_mask, double *tex_mask, double *step,
+                      float *c21_pre, float *c21_post,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- individual stages (bench.py times the dominant kernel with these) --------------------
+ * analyze : frames -> per-block records (the kernel shared by embed and detect)
+ * apply   : frames + per-block coefficient deltas -> marked frames                          */
+int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int ofmk_stage_apply_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* Device-to-device streaming copy with 16-byte accesses; bench.py uses it to measure the
+ * achievable HBM bandwidth of the device in the same run as the kernels. */
+int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream);
+
+/* Tunables (process-wide, set before launching): tiles per workgroup for the analyze/apply
+ * kernels; <= 0 restores the default. */
+void ofmk_set_tiles_per_workgroup(int analyze_tiles, int apply_tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFFMARK_HIP_H */

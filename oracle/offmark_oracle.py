@@ -70,17 +70,53 @@ def _dct_matrix() -> np.ndarray:
 DCT_D = _dct_matrix()          # DCT_D[k, n], orthonormal DCT-II basis
 
 
-def _apply_last(x: np.ndarray, m: np.ndarray) -> np.ndarray:
-    """out[..., k] = sum_n x[..., n] * m[k, n], accumulated n-ascending in float64.
+def _c(k: int) -> float:
+    return math.cos(k * math.pi / 16.0)
 
-    Written as explicit elementwise ops so that a batch of one block and a batch of
-    32 400 blocks perform the identical arithmetic (BLAS may not)."""
+
+def _dct1d_last(x: np.ndarray) -> np.ndarray:
+    """Orthonormal 8-point DCT-II along the last axis, float64, even/odd butterfly form.
+
+    The butterflies (x[n] +- x[7-n]) make every AC output of a constant or mirror-symmetric
+    input an exact zero, as FFT-structured implementations such as OpenCV's do; a plain
+    matrix product would leave ~1e-17 residue whose SIGN the reference's QIM then amplifies
+    to a full quantisation step (dct_encoder.py:33-35, np.sign)."""
+    x0, x1, x2, x3, x4, x5, x6, x7 = (x[..., n] for n in range(8))
+    a0, a1, a2, a3 = x0 + x7, x1 + x6, x2 + x5, x3 + x4
+    b0, b1, b2, b3 = x0 - x7, x1 - x6, x2 - x5, x3 - x4
+    e0, e1, e2, e3 = a0 + a3, a1 + a2, a0 - a3, a1 - a2
     out = np.empty_like(x)
-    for k in range(8):
-        acc = x[..., 0] * m[k, 0]
-        for n in range(1, 8):
-            acc = acc + x[..., n] * m[k, n]
-        out[..., k] = acc
+    s0 = math.sqrt(0.125)
+    out[..., 0] = (e0 + e1) * s0
+    out[..., 4] = (e0 - e1) * (0.5 * _c(4))
+    out[..., 2] = 0.5 * (e2 * _c(2) + e3 * _c(6))
+    out[..., 6] = 0.5 * (e2 * _c(6) - e3 * _c(2))
+    out[..., 1] = 0.5 * (((b0 * _c(1) + b1 * _c(3)) + b2 * _c(5)) + b3 * _c(7))
+    out[..., 3] = 0.5 * (((b0 * _c(3) - b1 * _c(7)) - b2 * _c(1)) - b3 * _c(5))
+    out[..., 5] = 0.5 * (((b0 * _c(5) - b1 * _c(1)) + b2 * _c(7)) + b3 * _c(3))
+    out[..., 7] = 0.5 * (((b0 * _c(7) - b1 * _c(5)) + b2 * _c(3)) - b3 * _c(1))
+    return out
+
+
+def _idct1d_last(X: np.ndarray) -> np.ndarray:
+    """Inverse of _dct1d_last (DCT-III), same even/odd structure, float64."""
+    X0, X1, X2, X3, X4, X5, X6, X7 = (X[..., k] for k in range(8))
+    s0 = math.sqrt(0.125)
+    p0 = X0 * s0 + X4 * (0.5 * _c(4))          # (e0-sum terms)/..: even part, n-symmetric
+    p1 = X0 * s0 - X4 * (0.5 * _c(4))
+    q0 = 0.5 * (X2 * _c(2) + X6 * _c(6))
+    q1 = 0.5 * (X2 * _c(6) - X6 * _c(2))
+    ev0, ev3 = p0 + q0, p0 - q0                # even contribution to x0/x7 and x3/x4
+    ev1, ev2 = p1 + q1, p1 - q1                # ... x1/x6 and x2/x5
+    od0 = 0.5 * (((X1 * _c(1) + X3 * _c(3)) + X5 * _c(5)) + X7 * _c(7))
+    od1 = 0.5 * (((X1 * _c(3) - X3 * _c(7)) - X5 * _c(1)) - X7 * _c(5))
+    od2 = 0.5 * (((X1 * _c(5) - X3 * _c(1)) + X5 * _c(7)) + X7 * _c(3))
+    od3 = 0.5 * (((X1 * _c(7) - X3 * _c(5)) + X5 * _c(3)) - X7 * _c(1))
+    out = np.empty_like(X)
+    out[..., 0], out[..., 7] = ev0 + od0, ev0 - od0
+    out[..., 1], out[..., 6] = ev1 + od1, ev1 - od1
+    out[..., 2], out[..., 5] = ev2 + od2, ev2 - od2
+    out[..., 3], out[..., 4] = ev3 + od3, ev3 - od3
     return out
 
 
@@ -88,19 +124,19 @@ def dct8x8(blocks: np.ndarray) -> np.ndarray:
     """Orthonormal 2-D DCT-II of (..., 8, 8) float32 blocks -> float32.
 
     Stand-in for ``cv2.dct`` on an 8x8 CV_32F block (call sites dct_encoder.py:29,50,79;
-    dct_decoder.py:23,38,66).  Computed in float64 and rounded once to float32."""
+    dct_decoder.py:23,38,66).  Rows then columns in float64, rounded once to float32.
+    Elementwise NumPy ops only, so one block and 32 400 blocks do identical arithmetic."""
     x = np.asarray(blocks, dtype=F32).astype(F64)
-    t = _apply_last(x, DCT_D)                         # rows: along n (last axis)
-    t = np.swapaxes(_apply_last(np.swapaxes(t, -1, -2), DCT_D), -1, -2)   # columns
+    t = _dct1d_last(x)
+    t = np.swapaxes(_dct1d_last(np.swapaxes(t, -1, -2)), -1, -2)
     return t.astype(F32)
 
 
 def idct8x8(coeffs: np.ndarray) -> np.ndarray:
     """Orthonormal 2-D inverse DCT (DCT-III).  Stand-in for ``cv2.idct`` (dct_encoder.py:37)."""
     x = np.asarray(coeffs, dtype=F32).astype(F64)
-    dt = np.ascontiguousarray(DCT_D.T)
-    t = _apply_last(x, dt)
-    t = np.swapaxes(_apply_last(np.swapaxes(t, -1, -2), dt), -1, -2)
+    t = _idct1d_last(x)
+    t = np.swapaxes(_idct1d_last(np.swapaxes(t, -1, -2)), -1, -2)
     return t.astype(F32)
 
 
@@ -115,26 +151,35 @@ _I_GV = F32(-0.581)
 _I_R = F32(1.140)
 
 
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in float64, the sum is
+    rounded to float64 and then float32 (a double rounding that differs from a true fma with
+    probability ~2^-29 per operation)."""
+    return (np.asarray(a, F32).astype(F64) * np.asarray(b, F32).astype(F64) + np.asarray(c, F32).astype(F64)).astype(F32)
+
+
 def bgr2yuv_f32(img: np.ndarray) -> np.ndarray:
     """``cv2.cvtColor(f32, COLOR_BGR2YUV)`` stand-in (embedder.py:34, extractor.py:31).
 
     Channel 0 is treated as "B" whatever the caller put there (the reference feeds
-    rgb24 frames, frame_reader.py:47) -- indices, not colour names, matter."""
+    rgb24 frames, frame_reader.py:47) -- indices, not colour names, matter.
+    Operation order follows OpenCV's vectorised float path (RGB2YCrCb_f, fused multiply-adds):
+    Y = fma(c0, .114, fma(c1, .587, c2*.299)); U = fma(c0 - Y, .492, .5); V = fma(c2 - Y, .877, .5)."""
     a = np.asarray(img, dtype=F32)
     c0, c1, c2 = a[..., 0], a[..., 1], a[..., 2]
-    y = (c0 * _C_Y[0] + c1 * _C_Y[1]) + c2 * _C_Y[2]
-    u = (c0 - y) * _C_U + _DELTA
-    v = (c2 - y) * _C_V + _DELTA
+    y = _fma32(c0, _C_Y[0], _fma32(c1, _C_Y[1], c2 * _C_Y[2]))
+    u = _fma32(c0 - y, _C_U, _DELTA)
+    v = _fma32(c2 - y, _C_V, _DELTA)
     return np.stack([y, u, v], axis=-1).astype(F32)
 
 
 def yuv2bgr_f32(img: np.ndarray) -> np.ndarray:
-    """``cv2.cvtColor(f32, COLOR_YUV2BGR)`` stand-in (embedder.py:36)."""
+    """``cv2.cvtColor(f32, COLOR_YUV2BGR)`` stand-in (embedder.py:36); YCrCb2RGB_f's fma form."""
     a = np.asarray(img, dtype=F32)
     y, u, v = a[..., 0], a[..., 1] - _DELTA, a[..., 2] - _DELTA
-    c0 = y + u * _I_B
-    c1 = (y + u * _I_GU) + v * _I_GV
-    c2 = y + v * _I_R
+    c0 = _fma32(u, _I_B, y)
+    c1 = _fma32(v, _I_GV, _fma32(u, _I_GU, y))
+    c2 = _fma32(v, _I_R, y)
     return np.stack([c0, c1, c2], axis=-1).astype(F32)
 
 

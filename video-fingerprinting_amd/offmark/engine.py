@@ -1,0 +1,184 @@
+"""Batch engine over the C ABI: device tensors in, device tensors out.
+
+This is the layer the plugin classes (DctEncoder / DctDecoder / Embedder / Extractor) and the
+multi-GPU driver sit on.  It owns one scratch tensor per (H, W, frames-in-flight) and enqueues
+work on torch's current stream; nothing here synchronises.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _hip
+
+# frames per internal chunk: a chunk's input (+ output) should stay inside the 256 MiB Infinity
+# Cache between the analyze pass and the apply pass (DESIGN.md "chunking").
+_CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 96 << 20))
+
+
+def default_chunk_frames(H: int, W: int) -> int:
+    return max(1, _CACHE_BUDGET_BYTES // (H * W * 3))
+
+
+class DctEngine:
+    """Enqueue embed / detect for batches of interleaved u8 frames [n, H, W, 3] on one GPU."""
+
+    def __init__(self, device=None, chunk_frames: int | None = None):
+        self.torch = _hip.require_gpu()
+        self.lib = _hip.load()
+        self.device = self.torch.device("cuda", self.torch.cuda.current_device()) if device is None \
+            else self.torch.device(device)
+        self.chunk_frames = chunk_frames
+        self._ws = {}
+
+    # -- scratch ------------------------------------------------------------------------------
+    def workspace(self, H: int, W: int, frames: int):
+        key = (H, W, frames)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.ofmk_workspace_bytes(frames, H, W)
+            if nbytes == 0:
+                raise _hip.HipError(f"bad frame size {H}x{W}")
+            ws = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+            self._ws = {key: ws}          # keep one; sizes rarely change within a job
+        return ws
+
+    def _chunk(self, n, H, W):
+        c = self.chunk_frames or default_chunk_frames(H, W)
+        return max(1, min(n, c))
+
+    def _check_frames(self, frames, dtype):
+        t = self.torch
+        if not (isinstance(frames, t.Tensor) and frames.is_cuda and frames.dtype == dtype
+                and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()):
+            raise ValueError(f"frames must be a contiguous CUDA tensor [n,H,W,3] of {dtype}")
+        n, H, W, _ = frames.shape
+        return n, H, W
+
+    def _wm(self, wm, N):
+        t = self.torch
+        if isinstance(wm, np.ndarray):
+            wm = t.from_numpy(np.ascontiguousarray(wm.reshape(-1, N)).astype(np.uint8)).to(self.device)
+        wm = wm.reshape(-1, N)
+        if wm.dtype != t.uint8 or not wm.is_cuda or not wm.is_contiguous():
+            wm = wm.to(device=self.device, dtype=t.uint8).contiguous()
+        return wm
+
+    def _rows(self, wm_row, n):
+        if wm_row is None:
+            return None
+        t = self.torch
+        if isinstance(wm_row, np.ndarray):
+            wm_row = t.from_numpy(wm_row.astype(np.int32))
+        wm_row = wm_row.to(device=self.device, dtype=t.int32).contiguous()
+        if wm_row.numel() != n:
+            raise ValueError("wm_row needs one entry per frame")
+        return wm_row
+
+    # -- u8 RGB batch path (the hot path) --------------------------------------------------------
+    def embed(self, frames, wm, alpha=20, wm_row=None, out=None):
+        """Mark every frame.  wm: (n_wm, N) 0/1 array or tensor; wm_row: per-frame row of wm."""
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        N = H * W // 64
+        wm = self._wm(wm, N)
+        rows = self._rows(wm_row, n)
+        if out is None:
+            out = t.empty_like(frames)
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
+                                            _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
+                                            _hip.current_stream()))
+        return out
+
+    def detect(self, frames, L, alpha=20, want_bits=False):
+        """Returns (counts int32 [n, L], bits u8 [n, N] or None)."""
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        N = H * W // 64
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_detect_rgb8(frames.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
+                                             _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
+        return counts, bits
+
+    def embed_detect(self, frames, wm, L, alpha=20, wm_row=None, out=None, want_bits=False):
+        """Mark, then read back the marked frames chunk by chunk (mark + verify)."""
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        N = H * W // 64
+        wm = self._wm(wm, N)
+        rows = self._rows(wm_row, n)
+        if out is None:
+            out = t.empty_like(frames)
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
+                                                   wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
+                                                   counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
+                                                   _hip.current_stream()))
+        return out, counts, bits
+
+    # -- float32 YUV path (the literal encode(yuv)/decode(yuv) plugin boundary) ------------------
+    def encode_yuv(self, yuv, wm, alpha=20, wm_row=None):
+        t = self.torch
+        n, H, W = self._check_frames(yuv, t.float32)
+        wm = self._wm(wm, H * W // 64)
+        rows = self._rows(wm_row, n)
+        cf = self._chunk(n, H, W * 4)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], _hip.ptr(rows),
+                                               float(alpha), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
+        return yuv
+
+    def decode_yuv(self, yuv, L=1, alpha=20, want_bits=True):
+        t = self.torch
+        n, H, W = self._check_frames(yuv, t.float32)
+        N = H * W // 64
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
+        cf = self._chunk(n, H, W * 4)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_decode_yuv32f(yuv.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
+                                               _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
+        return counts, bits
+
+    # -- parity planes ----------------------------------------------------------------------------
+    def debug_planes(self, frame, alpha=20, wm=None):
+        """One frame (u8 [H,W,3] or f32 YUV [H,W,3], CUDA).  Returns a dict of host numpy planes."""
+        t = self.torch
+        is_yuv = frame.dtype == t.float32
+        H, W, _ = frame.shape
+        h8, w8 = H // 8, W // 8
+        mk = lambda dt: t.empty((h8, w8), dtype=dt, device=self.device)  # noqa: E731
+        ydc, c21_pre, c21_post = mk(t.float32), mk(t.float32), mk(t.float32)
+        lum, tex, step = mk(t.float64), mk(t.float64), mk(t.float64)
+        wmt = self._wm(wm, H * W // 64) if wm is not None else None
+        ws = self.workspace(H, W, 1)
+        _hip.check(self.lib.ofmk_debug_planes(frame.contiguous().data_ptr(), int(is_yuv), H, W, float(alpha),
+                                              _hip.ptr(wmt), ydc.data_ptr(), lum.data_ptr(), tex.data_ptr(),
+                                              step.data_ptr(), c21_pre.data_ptr(),
+                                              c21_post.data_ptr() if wmt is not None else None,
+                                              ws.data_ptr(), ws.numel(), _hip.current_stream()))
+        out = dict(y_dc=ydc, lum=lum, tex=tex, step=step, c21_pre=c21_pre)
+        if wmt is not None:
+            out["c21_post"] = c21_post
+        return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def payload_means(counts: np.ndarray, N: int, L: int) -> np.ndarray:
+    """Host epilogue of DeShuffler.degenerate (de_shuffler.py:17-18): mean of bits[i::L].
+
+    counts[..., i] is the number of ones among the N-long bit vector's entries i, i+L, ...;
+    that slice has ceil((N - i) / L) entries (fewer than N/L for the tail when L does not divide N).
+    """
+    i = np.arange(L)
+    lens = np.where(i < N, (N - i + L - 1) // L, 0).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return counts.astype(np.float64) / lens
