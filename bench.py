@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- 1080p frames/s for DCT watermark embed+detect on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic frames resident in HBM:
+embed every frame, detect the produced frames, recover each frame's payload, all-gather the
+payloads over the ranks (RCCL; a no-op on one GPU) and take the cross-frame vote.
+Workload at N=1: BASELINE.json configs[1] -- 300 synthetic 1080p frames, payload
+[0,1,1,0,0,1,0,1], Shuffler(key=0), alpha=20.  With N ranks every rank holds its own 300 frames
+(weak scaling, frames shard with no data-path collective).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (analyze: it reads every
+frame once for embed and once for detect); durations come from HIP events recorded by the
+library around every launch on the launch stream during the timed steps.  `cpu_baseline` is the
+NumPy oracle (a port of the reference algorithm; OpenCV is not installed) on one host core.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "video-fingerprinting_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+PAYLOAD = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=300, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = engine default)")
+    ap.add_argument("--alpha", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket kernels with HIP events (roofline becomes null)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_u8, wm, alpha, budget_s):
+    """Oracle (NumPy port of the reference algorithm) embed+detect on a bounded sample, one core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import offmark_oracle as orc
+    enc = orc.DctEncoderOracle(alpha=alpha)
+    enc.read_wm(wm)
+    dec = orc.DctDecoderOracle(alpha=alpha)
+    done, t0, ok = 0, time.perf_counter(), True
+    for i in range(len(frames_u8)):
+        marked = orc.mark_frame(frames_u8[i], enc)
+        bits = orc.check_frame(marked, dec)
+        ok &= bool(np.array_equal(orc.deshuffle(bits, PAYLOAD.size, 0), PAYLOAD))
+        done += 1
+        el = time.perf_counter() - t0
+        if el + el / done > budget_s and done >= 2:
+            break
+    el = time.perf_counter() - t0
+    return dict(value=done / el, unit="frames/s", cores=1, kind="port",
+                sample=f"{done} of the workload's {frames_u8.shape[1]}x{frames_u8.shape[2]} frames, embed+detect, "
+                       f"vectorised NumPy oracle, {el:.1f} s; payload recovered: {ok}")
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from offmark import _hip
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.dist.vote import gather_payloads, init_from_env, vote_segments
+    from offmark.engine import DctEngine, default_chunk_frames
+    from offmark.generator.shuffler import Shuffler
+    from offmark.synthetic import synthetic_frames
+
+    rank, world = init_from_env("nccl")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _hip.load()
+
+    n, H, W = a.frames, a.height, a.width
+    N = H * W // 64
+    frames = synthetic_frames(n, H, W, seed=2000 + rank, device=dev)
+    out = torch.empty_like(frames)
+    wm = Shuffler(key=0).generate_wm(PAYLOAD, (1, N))
+    wm_dev = torch.from_numpy(wm.astype(np.uint8)).to(dev)
+    deg = DeShuffler(key=0).set_shape(PAYLOAD.shape)
+    chunk = a.chunk or default_chunk_frames(H, W)
+    eng = DctEngine(device=dev, chunk_frames=chunk)
+    seg_ids = np.repeat(np.arange(world), n)             # one segment per rank
+
+    perm_dev = torch.as_tensor(deg.payload_idx, dtype=torch.int32).to(dev)
+    host = [torch.empty((world * n, PAYLOAD.size), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]
+
+    def enqueue(k):
+        """GPU half of step k: embed, detect the marked frames, per-frame payloads, all-gather."""
+        _, counts, _ = eng.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=out)
+        mine = eng.payloads(counts, N, perm_dev)                         # [n, L] uint8, on device
+        everyone = gather_payloads(mine)                                 # RCCL all-gather (N > 1)
+        host[k & 1].copy_(everyone, non_blocking=True)
+        ready[k & 1].record()
+        return mine
+
+    def finish(k):
+        """Host half of step k: the reference's cross-frame Counter vote, once its payloads have landed.
+        It runs while the GPU is already working on step k+1 (double-buffered)."""
+        ready[k & 1].synchronize()
+        return vote_segments(host[k & 1].numpy(), seg_ids)
+
+    def run(steps):
+        votes, mine = None, None
+        for k in range(steps):
+            mine = enqueue(k)
+            if k:
+                votes = finish(k - 1)
+        return finish(steps - 1), mine
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup:
+        run(a.warmup)
+    launches_per_step = 5 * ((n + chunk - 1) // chunk)      # upper bound (4 with the fused verify kernel)
+    use_events = not a.no_kernel_events
+    if use_events:
+        _hip.check(lib.ofmk_timing_enable(launches_per_step * a.steps + 16))
+    fence()
+    t0 = time.perf_counter()
+    votes, mine = run(a.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern = None
+    if use_events:
+        ms = (ctypes.c_double * 4)()
+        cnt = (ctypes.c_int * 4)()
+        _hip.check(lib.ofmk_timing_collect(ms, cnt))
+        lib.ofmk_timing_disable()
+        kern = {k: dict(ms_total=ms[i], launches=cnt[i])
+                for i, k in enumerate(("analyze", "finalize", "mark", "mark_fused"))}
+
+    # correctness of what was timed: every frame's payload, every segment's vote
+    payload_ok = bool((mine.cpu().numpy() == PAYLOAD[None]).all())
+    votes_ok = all(v[0] is not None and np.array_equal(v[0], PAYLOAD) for v in votes.values())
+    ber = float((mine.cpu().numpy() != PAYLOAD[None]).mean())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # achievable HBM bandwidth of this device, same run: 16-byte streaming copy, read + write
+    nbytes = frames.numel() // 16 * 16
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s = _hip.current_stream()
+    for _ in range(2):
+        _hip.check(lib.ofmk_hbm_copy(frames.data_ptr(), out.data_ptr(), nbytes, s))
+    e0.record()
+    for _ in range(5):
+        _hip.check(lib.ofmk_hbm_copy(frames.data_ptr(), out.data_ptr(), nbytes, s))
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 5 * 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    fps = world * n * a.steps / elapsed
+    frame_bytes = 3 * H * W
+    roof = None
+    extra = {}
+    if kern:
+        # algorithmic bytes per frame and kernel: analyze reads the frame (3 B/px);
+        # mark reads it again and writes the marked frame (6 B/px); the fused mark+verify kernel
+        # moves the same 6 B/px and spares detect's 3 B/px read.  Sum over a step = 9 B/px.
+        alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes}
+        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>"}
+        per = {}
+        for k, v in kern.items():
+            if not v["launches"]:
+                continue
+            avg_ms = v["ms_total"] / v["launches"]
+            d = dict(avg_launch_ms=round(avg_ms, 5), launches=v["launches"], ms_per_step=round(v["ms_total"] / a.steps, 4))
+            if k in alg:
+                frames_per_launch = v.get("frames", n * a.steps * (2 if (k == "analyze" and not kern["mark_fused"]["launches"]) else 1)) / v["launches"]
+                d["algorithmic_bytes_per_launch"] = int(frames_per_launch * alg[k])
+                d["achieved_GBps"] = round(frames_per_launch * alg[k] / (avg_ms * 1e-3) / 1e9, 1)
+            per[k] = d
+        extra["kernels"] = per
+        extra["kernel_ms_per_step"] = round(sum(v["ms_total"] for v in kern.values()) / a.steps, 4)
+        dom = max((k for k in per if k in alg), key=lambda k: per[k]["ms_per_step"])
+        achieved = per[dom]["achieved_GBps"]
+        roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=per[dom]["algorithmic_bytes_per_launch"],
+                    avg_launch_ms=per[dom]["avg_launch_ms"], launches=per[dom]["launches"],
+                    frac_of_measured_copy=round(achieved / copy_gbps, 4))
+
+    base = None
+    if world == 1 and not a.no_cpu_baseline:
+        base = cpu_baseline(frames[:16].cpu().numpy(), wm, a.alpha, a.cpu_seconds)
+
+    path_gbps = fps * 9 * H * W / 1e9                                   # 9 B/px per embed+detect frame
+    line = {
+        "metric": "1080p frames/sec embed+detect" if (H, W) == (1080, 1920) else f"{W}x{H} frames/sec embed+detect",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {W}x{H} u8 RGB x{n} frames per GPU, DCT embed+detect+vote "
+                               "(BASELINE.json configs[1])",
+                   "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
+                   "chunk_frames": chunk, "sharding": f"frames, {world} rank(s), one RCCL all-gather of payloads"},
+        "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,
+        "roofline": roof,
+        "path": {"algorithmic_GBps": round(path_gbps, 1), "bytes_per_frame": 9 * H * W,
+                 "frac_of_peak": round(path_gbps / (HBM_PEAK_GBPS * world), 4),
+                 "frac_of_measured_copy": round(path_gbps / (copy_gbps * world), 4)},
+        "hbm_copy_GBps": round(copy_gbps, 1),
+        "cpu_baseline": base,
+    }
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,7 @@
  *   - every pointer marked "device" is HBM memory owned by the caller (e.g. torch tensors);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is only
  *     ENQUEUED on it: no allocation, no host synchronisation, no internal threads, so every
- *     call except ofmk_stage_times_ms() may be captured into a hipGraph;
+ *     compute call may be captured into a hipGraph (the ofmk_timing_* helpers are host-side);
  *   - return value 0 = OK, negative = error (OFMK_E_*); ofmk_last_error() gives the text for
  *     the calling thread; nothing throws across this boundary;
  *   - frames are interleaved 8-bit, 3 channels, row-major [n][H][W][3] exactly as
@@ -77,6 +77,13 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                            int L, int32_t *counts, uint8_t *bits,
                            int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- DeShuffler.degenerate's epilogue for a batch, on the device ---------------------------
+ * src/offmark/degenerator/de_shuffler.py:17-22: mean of bits[i::L] (from `counts`), undo the key
+ * permutation (`perm` = DeShuffler.payload_idx, device int32 [L]), threshold strictly above the
+ * mid-range of the L means.  payload: device u8 [n][L].  n_bits = H*W/64.                   */
+int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm,
+                              uint8_t *payload, void *stream);
+
 /* ---- plugin-level entry points on float32 YUV frames --------------------------------------
  * DctEncoder.encode(yuv) (dct_encoder.py:18-39; mutates channel 1 in place) and
  * DctDecoder.decode(yuv) (dct_decoder.py:10-27).  yuv: device f32 [n][H][W][3].            */
@@ -98,21 +105,30 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
                       float *c21_pre, float *c21_post,
                       void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- individual stages (bench.py times the dominant kernel with these) --------------------
+/* ---- individual stages (bench.py and tests drive single kernels with these) ----------------
  * analyze : frames -> per-block records (the kernel shared by embed and detect)
- * apply   : frames + per-block coefficient deltas -> marked frames                          */
+ * mark    : frames + the per-block coefficient deltas left in the workspace by the last embed ->
+ *           marked frames; fused != 0 also analyzes the marked frames (mark + verify kernel)   */
 int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W,
                             void *workspace, size_t workspace_bytes, void *stream);
-int ofmk_stage_apply_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
-                          void *workspace, size_t workspace_bytes, void *stream);
+int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int fused,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Device-to-device streaming copy with 16-byte accesses; bench.py uses it to measure the
  * achievable HBM bandwidth of the device in the same run as the kernels. */
 int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream);
 
-/* Tunables (process-wide, set before launching): tiles per workgroup for the analyze/apply
- * kernels; <= 0 restores the default. */
-void ofmk_set_tiles_per_workgroup(int analyze_tiles, int apply_tiles);
+/* Per-launch HIP-event timing for bench.py.  enable() pre-creates 2*max_launches events; while
+ * enabled every kernel launch is bracketed by hipEventRecord on the launch stream; collect()
+ * waits for the recorded events, returns the summed milliseconds and launch counts per kernel
+ * kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze) and rewinds the pool.  Not for use under graph capture. */
+int ofmk_timing_enable(int max_launches);
+int ofmk_timing_collect(double *ms_by_kind /*[4]*/, int *launches_by_kind /*[4]*/);
+void ofmk_timing_disable(void);
+
+/* Process-wide switch for ofmk_embed_detect_rgb8: 1 (default) marks and analyzes the marked block
+ * in one kernel; 0 runs the separate mark and analyze kernels (same results bit for bit). */
+void ofmk_set_fused_verify(int on);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 // offmark_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels + C ABI for the offmark
-// DCT frame-watermark path.  Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// DCT frame-watermark path.  Built with:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize
 //
 // Reference behaviour restated here (paths relative to the reference root):
 //   src/offmark/video/embedder.py:33-39      u8 -> f32 -> "BGR2YUV" -> encode -> "YUV2BGR" -> clip/round/u8
@@ -7,22 +8,24 @@
 //   src/offmark/extract/dct_decoder.py:10-27 same masks, bit = round(c21/step) odd
 //   src/offmark/degenerator/de_shuffler.py:17-18  sums of bits[i::L] (the mean's numerator)
 //
-// Three kernels (DESIGN.md has the full story):
+// Kernels (DESIGN.md has the full story):
 //   analyze  : frame pixels -> 5 floats per 8x8 block {A00, sum|A|, dcl, e, C21} + a fixed-point
-//              sum of the block means (frame-global mean needed by the luminance mask).
-//              Shared by embed and detect.  HBM-bound: 3 B/px in, 0.31 B/px out.
+//              sum of the block DCs (the luminance mask needs the frame-global mean first).
+//              Shared by embed and detect.  Reads 3 B/px, writes 0.31 B/px.
 //   finalize : one thread per block: luminance/texture masks (float64 like the reference), step,
 //              then either the QIM delta of C21 (embed) or the read-out bit + bits[i::L] counts.
-//   apply    : frame pixels + delta -> marked pixels.  Because the 8x8 DCT is orthonormal,
+//   mark     : frame pixels + delta -> marked pixels.  The 8x8 DCT is orthonormal, so
 //              idct(dct(U) + d*e21) == U + d * outer(c2, c1): a rank-1 update, no DCT needed.
+//              The FUSED variant also analyzes the marked block it has just produced (mark +
+//              verify), which saves detect's read of the marked frame.
 //
-// Thread roles in analyze (256 threads = 4 wavefronts of 64, tile = 8 pixel rows x 32 blocks):
-//   phase 1: thread (r = t>>5, b = t&31) owns pixel row r of block b: 24 contiguous bytes.  A
-//            32-lane half-wave therefore reads 768 contiguous bytes.  Row DCT in registers.
-//   LDS    : thread t stores its 8 row-DCT outputs at T[t*8 .. t*8+7] (two ds_write_b128).
-//   phase 2: thread (b = t>>3, j = t&7) owns coefficient column j of block b and reads
-//            T[i*256 + t], i = 0..7 (eight conflict-free ds_read_b32).  Column DCT in registers,
-//            8-lane DPP butterflies for the per-block sums (no LDS, no bpermute).
+// Work decomposition: ONE THREAD PER 8x8 BLOCK.  A lane owns 8 rows x 24 contiguous bytes; the 64
+// lanes of a wavefront own 64 adjacent blocks, so every row load of a wave covers 1536 contiguous
+// bytes.  Row DCTs, column DCTs and all per-block sums stay in that lane's registers: no LDS, no
+// barrier, no cross-lane traffic.  (A first version staged the 8x8 transpose through LDS with
+// 8-lane DPP sums; rocprofv3 showed VALU ~58 % and the LDS pipe ~55 % busy at once -- see
+// profiles/ -- and this form needs ~20 % fewer VALU instructions and none of the LDS ones.)
+// It also lets the texture-feature sums follow numpy's exact association order.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -34,10 +37,23 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileBlocks = 32;   // blocks per tile
-constexpr int kRec = 5;           // floats per block record
+constexpr int kRec = 5;           // float planes per block record: A00, sum|A|, dcl, e, C21
 constexpr int kSlots = 32;        // fixed-point mean accumulators per frame (spreads atomics)
 constexpr int kHistMax = 2048;    // payload lengths up to this use an LDS histogram in finalize
+
+// minimum waves per SIMD the register allocator must leave room for (tuned on MI355X, profiles/)
+#ifndef OFMK_ANALYZE_WAVES
+#define OFMK_ANALYZE_WAVES 4
+#endif
+#ifndef OFMK_PREFETCH_ROWS
+#define OFMK_PREFETCH_ROWS 4
+#endif
+#ifndef OFMK_ROW_BARRIER
+#define OFMK_ROW_BARRIER 1
+#endif
+#ifndef OFMK_FUSED_WAVES
+#define OFMK_FUSED_WAVES 3
+#endif
 
 constexpr int SRC_RGB8 = 0;
 constexpr int SRC_YUV32F = 1;
@@ -50,12 +66,15 @@ constexpr float H1 = 0.49039264f, H2 = 0.46193977f, H3 = 0.41573481f, H4 = 0.353
 constexpr float KY0 = 0.114f, KY1 = 0.587f, KY2 = 0.299f, KU = 0.492f, KV = 0.877f, KDELTA = 0.5f;
 constexpr float KI_B = 2.032f, KI_GU = -0.395f, KI_GV = -0.581f;
 
-__constant__ float kC2[8] = {H2, H6, -H6, -H2, -H2, -H6, H6, H2};   // 0.5*cos((2r+1)*2*pi/16)
-__device__ __forceinline__ constexpr float c1_of(int x) {               // 0.5*cos((2x+1)*1*pi/16)
+__device__ __forceinline__ constexpr float c1_of(int x) {   // 0.5*cos((2x+1)*1*pi/16): row basis of [2][1]
     return x == 0 ? H1 : x == 1 ? H3 : x == 2 ? H5 : x == 3 ? H7 : x == 4 ? -H7 : x == 5 ? -H5 : x == 6 ? -H3 : -H1;
 }
+__device__ __forceinline__ constexpr float c2_of(int r) {   // 0.5*cos((2r+1)*2*pi/16): column basis of [2][1]
+    return (r == 0 || r == 7) ? H2 : (r == 1 || r == 6) ? H6 : (r == 2 || r == 5) ? -H6 : -H2;
+}
 
-// In-place orthonormal 8-point DCT-II, even/odd decomposition: 36 VALU ops.
+// In-place orthonormal 8-point DCT-II, even/odd decomposition: 36 VALU ops.  The first butterfly
+// stage makes every AC output of a constant or mirror-symmetric input an exact zero.
 __device__ __forceinline__ void dct8(float (&x)[8]) {
     const float a0 = x[0] + x[7], a1 = x[1] + x[6], a2 = x[2] + x[5], a3 = x[3] + x[4];
     const float b0 = x[0] - x[7], b1 = x[1] - x[6], b2 = x[2] - x[5], b3 = x[3] - x[4];
@@ -70,23 +89,14 @@ __device__ __forceinline__ void dct8(float (&x)[8]) {
     x[7] = fmaf(b3, -H1, fmaf(b2, H3, fmaf(b1, -H5, b0 * H7)));
 }
 
-// sum_x v[x] * 0.5*cos((2x+1)*pi/16): coefficient 1 of the 8-point DCT only (8 ops)
+// coefficient 1 of the 8-point DCT only (8 ops), butterfly first
 __device__ __forceinline__ float proj1(const float (&v)[8]) {
     return fmaf(v[3] - v[4], H7, fmaf(v[2] - v[5], H5, fmaf(v[1] - v[6], H3, (v[0] - v[7]) * H1)));
 }
-
-// DPP lane exchange inside groups of 8 lanes (wave64: rows of 16 lanes, quads of 4).
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-// After this every lane of an aligned 8-lane group holds ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)),
-// which is also numpy's combine order for the 8 running sums of np.sum on 64 floats.
-__device__ __forceinline__ float sum8(float v) {
-    v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp<0x141>(v);   // row_half_mirror
-    return v;
+// coefficient 2 of the 8-point DCT only, same association as dct8's x[2]
+__device__ __forceinline__ float proj2(const float (&v)[8]) {
+    const float a0 = v[0] + v[7], a1 = v[1] + v[6], a2 = v[2] + v[5], a3 = v[3] + v[4];
+    return fmaf(a1 - a2, H6, (a0 - a3) * H2);
 }
 
 __device__ __forceinline__ void divmod_small(int c, int d, float inv_d, int &q, int &r) {
@@ -94,6 +104,18 @@ __device__ __forceinline__ void divmod_small(int c, int d, float inv_d, int &q, 
     r = c - q * d;
     if (r < 0) { q -= 1; r += d; }
     else if (r >= d) { q += 1; r -= d; }
+}
+
+// Sum of one int per lane over the 64-lane wavefront; result is wave-uniform (an SGPR).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int wave_sum(int v) {
+    v += dpp_i<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_i<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_i<0x141>(v);    // row_half_mirror
+    v += dpp_i<0x140>(v);    // row_mirror: every lane of a 16-lane row now holds the row sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -134,171 +156,158 @@ __device__ __forceinline__ float px_byte(const Px8 &v, int k) {   // k is a comp
     return (float)((v.w[k >> 2] >> (8 * (k & 3))) & 0xffu);       // -> v_cvt_f32_ubyteN
 }
 
-struct Yuv8 { float4 q[6]; };    // 8 interleaved f32 YUV pixels = 96 bytes
-
-template <bool ALIGNED>
-__device__ __forceinline__ Yuv8 load_yuv8(const float *p) {
-    Yuv8 v;
-    if constexpr (ALIGNED) {
-        const float4 *q = reinterpret_cast<const float4 *>(p);
+// cvtColor BGR2YUV for one 8-pixel row, per pixel and in OpenCV's fma order, so that a chroma-flat
+// block yields bit-identical U samples and hence an exactly zero C21 (np.sign(0) == 0).
+__device__ __forceinline__ void row_yu(const Px8 &px, float (&y)[8], float (&u)[8]) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v.q[k] = q[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v.q[k] = make_float4(p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]);
+    for (int x = 0; x < 8; ++x) {
+        const float c0 = px_byte(px, 3 * x);
+        y[x] = fmaf(c0, KY0, fmaf(px_byte(px, 3 * x + 1), KY1, px_byte(px, 3 * x + 2) * KY2));
+        u[x] = fmaf(c0 - y[x], KU, KDELTA);
     }
-    return v;
-}
-__device__ __forceinline__ float yuv_elem(const Yuv8 &v, int k) {
-    const float4 &f = v.q[k >> 2];
-    return (k & 3) == 0 ? f.x : (k & 3) == 1 ? f.y : (k & 3) == 2 ? f.z : f.w;
 }
 
-template <int SRC> struct RawOf;
-template <> struct RawOf<SRC_RGB8> { using type = Px8; };
-template <> struct RawOf<SRC_YUV32F> { using type = Yuv8; };
+// ------------------------------------------------------------------------------------------
+// geometry and per-block features
+// ------------------------------------------------------------------------------------------
+struct Geom {
+    int W;                // pixels per row
+    int wb;               // blocks per block-row (W / 8)
+    float inv_wb;
+    int nblk;             // (H/8)*(W/8)
+    size_t frame_stride;  // elements (bytes for u8, floats for f32) between frames
+    size_t plane;         // elements between record planes (frames in flight * nblk)
+};
+
+struct BlockFeat { float a00, tot, dcl, e, c21; };
+
+// R[r][k]: row-DCT outputs of the Y block (row r, horizontal frequency k); u1[r]: k=1 projection
+// of the U rows.  Column DCTs in place, then the texture-mask features with the reference's own
+// association order (dct_encoder.py:80-86; np.sum = 8 running column sums combined pairwise).
+__device__ __forceinline__ BlockFeat block_features(float (&R)[8][8], const float (&u1)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float col[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[i] = R[i][j];
+        dct8(col);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) R[i][j] = col[i];
+    }
+    BlockFeat ft;
+    ft.a00 = R[0][0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) R[i][j] = fabsf(R[i][j]);
+    float rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        rs[j] = R[0][j];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) rs[j] += R[i][j];
+    }
+    ft.tot = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+    ft.dcl = ((((R[0][0] + R[0][1]) + R[0][2]) + R[1][0]) + R[1][1]) + R[2][0];
+    ft.e = ((((((((((R[3][0] + R[4][0]) + R[5][0]) + R[6][0]) + R[0][3]) + R[0][4]) + R[0][5]) + R[0][6]) +
+              R[2][1]) + R[1][2]) + R[2][2]) + R[3][3];
+    ft.c21 = proj2(u1);
+    return ft;
+}
+
+// Records are five planes of [frames][nblk] floats; the frame's block DCs also go, as 2^19 fixed
+// point, into one of kSlots 64-bit accumulators: integer adds commute, so the frame mean is
+// bit-reproducible however the workgroups are scheduled.
+__device__ __forceinline__ void emit_block(const BlockFeat &ft, bool valid, int f, int c, const Geom &g,
+                                           float *__restrict__ rec, unsigned long long *__restrict__ ysum) {
+    if (valid) {
+        float *r = rec + (size_t)f * g.nblk + c;
+        r[0] = ft.a00;
+        r[g.plane] = ft.tot;
+        r[2 * g.plane] = ft.dcl;
+        r[3 * g.plane] = ft.e;
+        r[4 * g.plane] = ft.c21;
+    }
+    const int q = valid ? __float2int_rn(ft.a00 * 524288.0f) : 0;     // A00 * 2^19, |A00| <= 2040
+    const int lo = wave_sum(q & 0xffff), hi = wave_sum(q >> 16);
+    if ((threadIdx.x & 63) == 0) {
+        const long long s = (long long)hi * 65536 + lo;
+        const int slot = (blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6)) & (kSlots - 1);
+        if (s != 0) atomicAdd(&ysum[(size_t)f * kSlots + slot], (unsigned long long)s);
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // analyze
 // ------------------------------------------------------------------------------------------
-struct Geom {
-    int W;                // pixels per row
-    int wb;               // blocks per block-row  (W / 8)
-    float inv_wb;
-    int nblk;             // (H/8)*(W/8)
-    int tiles_per_frame;  // ceil(nblk / 32)
-    int total_tiles;      // frames * tiles_per_frame
-    int tiles_per_wg;
-    size_t frame_stride;  // elements (bytes for u8, floats for f32) between frames
-};
-
 template <int SRC, bool ALIGNED>
-__device__ __forceinline__ typename RawOf<SRC>::type
-load_block_row(const void *frames, const Geom &g, int f, int tb, int r, int b) {
-    int c = tb * kTileBlocks + b;
-    c = c < g.nblk ? c : g.nblk - 1;              // clamp: the lane computes a duplicate, never stores it
-    int bi, bj;
-    divmod_small(c, g.wb, g.inv_wb, bi, bj);
-    const size_t off = (size_t)f * g.frame_stride + ((size_t)(bi * 8 + r) * g.W + (size_t)bj * 8) * 3;
-    if constexpr (SRC == SRC_RGB8) return load_px8<ALIGNED>(static_cast<const uint8_t *>(frames) + off);
-    else return load_yuv8<ALIGNED>(static_cast<const float *>(frames) + off);
-}
-
-template <int SRC, bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void analyze_kernel(const void *__restrict__ frames, Geom g,
+__global__ __launch_bounds__(kThreads, OFMK_ANALYZE_WAVES) void analyze_kernel(const void *__restrict__ frames, Geom g,
                                                            float *__restrict__ rec,
                                                            unsigned long long *__restrict__ ysum) {
-    __shared__ __attribute__((aligned(16))) float T[2][kThreads * 8];   // row-DCT outputs, double buffered
-    __shared__ float U1[2][kThreads];                                   // per-row k=1 projection of U
-
-    const int t = threadIdx.x;
-    const int r1 = t >> 5, b1 = t & 31;   // phase-1 role
-    const int b2 = t >> 3, j = t & 7;     // phase-2 role
-
-    // 0/1 lane weights selecting this lane's contribution to dcl and e (texture mask features,
-    // dct_encoder.py:81,84-86).  Lane j holds column j: a[i] = |A[i][j]|.
-    const float wd0 = j <= 2 ? 1.f : 0.f, wd1 = j <= 1 ? 1.f : 0.f, wd2 = j == 0 ? 1.f : 0.f;
-    const float we0 = (j >= 3 && j <= 6) ? 1.f : 0.f;          // (0,3) (0,4) (0,5) (0,6)
-    const float we1 = j == 2 ? 1.f : 0.f;                        // (1,2)
-    const float we2 = (j == 1 || j == 2) ? 1.f : 0.f;            // (2,1) (2,2)
-    const float we3 = (j == 0 || j == 3) ? 1.f : 0.f;            // (3,0) (3,3)
-    const float we456 = j == 0 ? 1.f : 0.f;                      // (4,0) (5,0) (6,0)
-    const float c2j = kC2[j];
-
-    const int tile0 = blockIdx.x * g.tiles_per_wg;
-    int tile_end = tile0 + g.tiles_per_wg;
-    tile_end = tile_end < g.total_tiles ? tile_end : g.total_tiles;
-    if (tile0 >= tile_end) return;
-
-    // (frame, tile-in-frame) of the current tile and of the prefetched one, advanced incrementally
-    int f = tile0 / g.tiles_per_frame, tb = tile0 - f * g.tiles_per_frame;
-    int fn = f, tbn = tb;
-    long long acc = 0;          // fixed-point (2^-32) sum of block means A00/8, lanes j == 0 only
-    int acc_frame = f;
-
-    auto flush = [&](int frame) {
-        long long v = acc;
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if ((t & 63) == 0 && v != 0) {
-            const int slot = (blockIdx.x * 4 + (t >> 6)) & (kSlots - 1);
-            atomicAdd(&ysum[(size_t)frame * kSlots + slot], (unsigned long long)v);
-        }
-        acc = 0;
-    };
-
-    auto raw = load_block_row<SRC, ALIGNED>(frames, g, f, tb, r1, b1);
-    int buf = 0;
-    for (int tile = tile0; tile < tile_end; ++tile, buf ^= 1) {
-        auto cur = raw;
-        if (++tbn == g.tiles_per_frame) { tbn = 0; ++fn; }
-        if (tile + 1 < tile_end) raw = load_block_row<SRC, ALIGNED>(frames, g, fn, tbn, r1, b1);
-
-        // ---- phase 1: colour transform + row DCT of Y, k=1 projection of U -----------------
-        float y[8], u1;
-        if constexpr (SRC == SRC_RGB8) {
-            // cvtColor BGR2YUV, per pixel and in OpenCV's fma order, so that a chroma-flat block
-            // yields bit-identical U samples and hence an exactly zero C21 (np.sign(0) == 0)
-            float u[8];
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    int bi, bj;
+    divmod_small(valid ? c : g.nblk - 1, g.wb, g.inv_wb, bi, bj);     // ragged tail recomputes the last block
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    float R[8][8], u1[8];
+    if constexpr (SRC == SRC_RGB8) {
+        const uint8_t *p = static_cast<const uint8_t *>(frames) + off;
+        // rolling prefetch: OFMK_PREFETCH_ROWS rows of raw bytes in flight, each row consumed (colour
+        // transform + row DCT) as a unit; the scheduling barrier keeps the compiler from hoisting
+        // every row's conversions to the top, which costs ~200 VGPRs and half the occupancy.
+        Px8 raw[8];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const float c0 = px_byte(cur, 3 * x);
-                y[x] = fmaf(c0, KY0, fmaf(px_byte(cur, 3 * x + 1), KY1, px_byte(cur, 3 * x + 2) * KY2));
-                u[x] = fmaf(c0 - y[x], KU, KDELTA);
+        for (int r = 0; r < OFMK_PREFETCH_ROWS; ++r) raw[r] = load_px8<ALIGNED>(p + (size_t)r * pitch);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r + OFMK_PREFETCH_ROWS < 8)
+                raw[r + OFMK_PREFETCH_ROWS] = load_px8<ALIGNED>(p + (size_t)(r + OFMK_PREFETCH_ROWS) * pitch);
+            float y[8], u[8];
+            row_yu(raw[r], y, u);
+            u1[r] = proj1(u);
+            dct8(y);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) R[r][k] = y[k];
+#if OFMK_ROW_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    } else {
+        const float *p = static_cast<const float *>(frames) + off;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float y[8], u[8];
+            const float *q = p + (size_t)r * pitch;
+            if constexpr (ALIGNED) {
+                const float4 *q4 = reinterpret_cast<const float4 *>(q);
+                float4 v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[k] = q4[k];
+                const float *e = reinterpret_cast<const float *>(v);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { y[x] = e[3 * x]; u[x] = e[3 * x + 1]; }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) { y[x] = q[3 * x]; u[x] = q[3 * x + 1]; }
             }
-            u1 = proj1(u);
+            u1[r] = proj1(u);
             dct8(y);
-        } else {
-            float u[8];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) { y[x] = yuv_elem(cur, 3 * x); u[x] = yuv_elem(cur, 3 * x + 1); }
-            u1 = proj1(u);
-            dct8(y);
+            for (int k = 0; k < 8; ++k) R[r][k] = y[k];
         }
-        float4 *dst = reinterpret_cast<float4 *>(&T[buf][t * 8]);
-        dst[0] = make_float4(y[0], y[1], y[2], y[3]);
-        dst[1] = make_float4(y[4], y[5], y[6], y[7]);
-        U1[buf][t] = u1;
-        __syncthreads();
-
-        // ---- phase 2: column DCT, per-block features ---------------------------------------
-        float a[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = T[buf][i * kThreads + t];
-        dct8(a);
-        const float a00 = a[0];                       // meaningful on lane j == 0
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = fabsf(a[i]);
-        float tot = a[0];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) tot += a[i];      // numpy's running sum r_j
-        float dcl = fmaf(wd2, a[2], fmaf(wd1, a[1], wd0 * a[0]));
-        float e = fmaf(we456, (a[4] + a[5]) + a[6], fmaf(we3, a[3], fmaf(we2, a[2], fmaf(we1, a[1], we0 * a[0]))));
-        float c21 = U1[buf][j * kTileBlocks + b2] * c2j;
-        tot = sum8(tot);
-        dcl = sum8(dcl);
-        e = sum8(e);
-        c21 = sum8(c21);
-
-        const int c = tb * kTileBlocks + b2;
-        const bool valid = c < g.nblk;
-        if (f != acc_frame) { flush(acc_frame); acc_frame = f; }      // wave-uniform
-        if (valid) {
-            if (j == 0) acc += __float2ll_rn(a00 * 536870912.0f);     // (A00/8) * 2^32
-            const float v = j == 0 ? a00 : j == 1 ? tot : j == 2 ? dcl : j == 3 ? e : c21;
-            if (j < kRec) rec[((size_t)f * g.nblk + c) * kRec + j] = v;
-        }
-        f = fn; tb = tbn;
     }
-    flush(acc_frame);
+    const BlockFeat ft = block_features(R, u1);
+    emit_block(ft, valid, f, c, g, rec, ysum);
 }
 
 // ------------------------------------------------------------------------------------------
 // finalize
 // ------------------------------------------------------------------------------------------
 struct FinArgs {
-    const float *rec;                 // [frames][nblk][5]
+    const float *rec;                 // 5 planes of [frames][nblk]
+    size_t plane;
     const unsigned long long *ysum;   // [frames][kSlots]
     int nblk, N, L;
     double alpha;
@@ -338,25 +347,26 @@ __device__ __forceinline__ double texture_mask(float a00abs, float tot, float dc
 
 __global__ __launch_bounds__(kThreads) void finalize_kernel(FinArgs p) {
     __shared__ int hist[kHistMax];
+    __shared__ double s_mean;
     const int t = threadIdx.x;
     const int f = blockIdx.y;
     const int c = blockIdx.x * kThreads + t;
     const bool use_hist = p.counts != nullptr && p.L <= kHistMax;
-    if (use_hist) {
+    if (use_hist)
         for (int k = t; k < p.L; k += kThreads) hist[k] = 0;
-        __syncthreads();
-    }
-    if (c < p.nblk) {
+    if (t < 64) {
         // frame-global mean of the block means (luminance_mask, dct_encoder.py:54-56)
-        long long s = 0;
-#pragma unroll 8
-        for (int k = 0; k < kSlots; ++k) s += (long long)p.ysum[(size_t)f * kSlots + k];
-        const double mean_m = ((double)s * (1.0 / 4294967296.0)) / (double)p.nblk;
-        const double mean = mean_m > 90.0 ? mean_m : 90.0;
+        long long s = t < kSlots ? (long long)p.ysum[(size_t)f * kSlots + t] : 0;
+#pragma unroll
+        for (int d = 1; d < kSlots; d <<= 1) s += __shfl_xor(s, d);
+        if (t == 0) s_mean = ((double)s * (1.0 / 4194304.0)) / (double)p.nblk;   // sum(A00 * 2^19) -> mean(A00 / 8)
+    }
+    __syncthreads();
+    if (c < p.nblk) {
+        const double mean = s_mean > 90.0 ? s_mean : 90.0;
         const double f_ref = 1.0 + (mean - 90.0) * 1.0 / 165.0;
-
-        const float *r = p.rec + ((size_t)f * p.nblk + c) * kRec;
-        const float a00 = r[0], tot = r[1], dcl = r[2], e = r[3], c21 = r[4];
+        const float *r = p.rec + (size_t)f * p.nblk + c;
+        const float a00 = r[0], tot = r[p.plane], dcl = r[2 * p.plane], e = r[3 * p.plane], c21 = r[4 * p.plane];
         const double m = (double)a00 / 8.0;
         double lum;
         if (m > mean) lum = 1.0 + (m - mean) / (255.0 - mean) * (2.0 - f_ref);
@@ -408,74 +418,122 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(FinArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// apply
+// mark
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t to_u8(float v) {   // np.clip(0,255) -> np.around -> uint8
-    v = fminf(fmaxf(v, 0.f), 255.f);
-    return (uint32_t)rintf(v);
+// np.clip(0,255) -> np.around (half to even) -> uint8, packed into byte `sel` of `word`:
+// v_cvt_pk_u8_f32 does exactly that in one instruction (probed on gfx950: tools/probe.hip).
+__device__ __forceinline__ uint32_t put_u8(float v, int sel, uint32_t word) {
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, word);
 }
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void apply_rgb8_kernel(const uint8_t *__restrict__ in,
-                                                              uint8_t *__restrict__ out, Geom g,
-                                                              const float *__restrict__ delta) {
-    const int t = threadIdx.x;
-    const int r = t >> 5, b = t & 31;
-    const float c2r = kC2[r];
-    const int tile0 = blockIdx.x * g.tiles_per_wg;
-    int tile_end = tile0 + g.tiles_per_wg;
-    tile_end = tile_end < g.total_tiles ? tile_end : g.total_tiles;
-    int f = tile0 / g.tiles_per_frame, tb = tile0 - f * g.tiles_per_frame - 1;
-    for (int tile = tile0; tile < tile_end; ++tile) {
-        if (++tb == g.tiles_per_frame) { tb = 0; ++f; }
-        const int c = tb * kTileBlocks + b;
-        if (c >= g.nblk) continue;
-        int bi, bj;
-        divmod_small(c, g.wb, g.inv_wb, bi, bj);
-        const size_t off = (size_t)f * g.frame_stride + ((size_t)(bi * 8 + r) * g.W + (size_t)bj * 8) * 3;
-        const Px8 px = load_px8<ALIGNED>(in + off);
-        const float dr = delta[(size_t)f * g.nblk + c] * c2r;
-        uint32_t q[24];
+// embedder.py:33-39 for one block per thread.  FUSED: also analyze the marked block (detect's
+// front end on the frame being written), producing its records and mean accumulator.
+template <bool ALIGNED, bool FUSED>
+__global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_rgb8_kernel(const uint8_t *__restrict__ in,
+                                                             uint8_t *__restrict__ out, Geom g,
+                                                             const float *__restrict__ delta,
+                                                             float *__restrict__ rec,
+                                                             unsigned long long *__restrict__ ysum) {
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    if (!FUSED && !valid) return;
+    const int cc = valid ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    const float d = delta[(size_t)f * g.nblk + cc];
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<ALIGNED>(in + off + (size_t)r * pitch);
+    float R[8][8], u1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const Px8 &px = raw[r];
+        const float dr = d * c2_of(r);
+        Px8 o = px;       // channel 2 bytes stay: Y + 1.140*(V-0.5) = c2 - 2.2e-4*(c2 - Y), |error| < 0.05
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const float c0 = px_byte(px, 3 * x), c1 = px_byte(px, 3 * x + 1), c2 = px_byte(px, 3 * x + 2);
             const float y = fmaf(c0, KY0, fmaf(c1, KY1, c2 * KY2));
             const float u = fmaf(c0 - y, KU, KDELTA);          // cvtColor BGR2YUV
             const float v = fmaf(c2 - y, KV, KDELTA);
-            const float u2 = fmaf(dr, c1_of(x), u);              // idct(dct(U) + d*e21) = U + d*c2[r]*c1[x]
+            const float u2 = fmaf(dr, c1_of(x), u);            // idct(dct(U) + d*e21) = U + d*c2[r]*c1[x]
             const float ud = u2 - KDELTA, vd = v - KDELTA;     // cvtColor YUV2BGR
-            q[3 * x] = to_u8(fmaf(ud, KI_B, y));
-            q[3 * x + 1] = to_u8(fmaf(vd, KI_GV, fmaf(ud, KI_GU, y)));
-            // channel 2 = Y + 1.140*(V-0.5) = c2 - 2.2e-4*(c2 - Y): |error| < 0.05, always rounds back to c2
-            q[3 * x + 2] = (px.w[(3 * x + 2) >> 2] >> (8 * ((3 * x + 2) & 3))) & 0xffu;
+            o.w[(3 * x) >> 2] = put_u8(fmaf(ud, KI_B, y), (3 * x) & 3, o.w[(3 * x) >> 2]);
+            o.w[(3 * x + 1) >> 2] = put_u8(fmaf(vd, KI_GV, fmaf(ud, KI_GU, y)), (3 * x + 1) & 3, o.w[(3 * x + 1) >> 2]);
         }
-        Px8 o;
+        if (valid) store_px8<ALIGNED>(out + off + (size_t)r * pitch, o);
+        if constexpr (FUSED) {
+            float y[8], u[8];
+            row_yu(o, y, u);           // what detect will see: the rounded, clipped u8 pixels
+            u1[r] = proj1(u);
+            dct8(y);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) o.w[k] = q[4 * k] | (q[4 * k + 1] << 8) | (q[4 * k + 2] << 16) | (q[4 * k + 3] << 24);
-        store_px8<ALIGNED>(out + off, o);
+            for (int k = 0; k < 8; ++k) R[r][k] = y[k];
+        }
+    }
+    if constexpr (FUSED) {
+        const BlockFeat ft = block_features(R, u1);
+        emit_block(ft, valid, f, c, g, rec, ysum);
     }
 }
 
 // DctEncoder.encode on float32 YUV: only channel 1 changes (dct_encoder.py:20,36-37)
-__global__ __launch_bounds__(kThreads) void apply_yuv32f_kernel(float *__restrict__ yuv, Geom g,
-                                                                const float *__restrict__ delta) {
-    const int t = threadIdx.x;
-    const int r = t >> 5, b = t & 31;
-    const float c2r = kC2[r];
-    const int tile0 = blockIdx.x * g.tiles_per_wg;
-    int tile_end = tile0 + g.tiles_per_wg;
-    tile_end = tile_end < g.total_tiles ? tile_end : g.total_tiles;
-    int f = tile0 / g.tiles_per_frame, tb = tile0 - f * g.tiles_per_frame - 1;
-    for (int tile = tile0; tile < tile_end; ++tile) {
-        if (++tb == g.tiles_per_frame) { tb = 0; ++f; }
-        const int c = tb * kTileBlocks + b;
-        if (c >= g.nblk) continue;
-        int bi, bj;
-        divmod_small(c, g.wb, g.inv_wb, bi, bj);
-        float *p = yuv + (size_t)f * g.frame_stride + ((size_t)(bi * 8 + r) * g.W + (size_t)bj * 8) * 3;
-        const float dr = delta[(size_t)f * g.nblk + c] * c2r;
+__global__ __launch_bounds__(kThreads) void mark_yuv32f_kernel(float *__restrict__ yuv, Geom g,
+                                                               const float *__restrict__ delta) {
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= g.nblk) return;
+    int bi, bj;
+    divmod_small(c, g.wb, g.inv_wb, bi, bj);
+    float *p = yuv + (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    const float d = delta[(size_t)f * g.nblk + c];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) p[3 * x + 1] = fmaf(dr, c1_of(x), p[3 * x + 1]);
+    for (int r = 0; r < 8; ++r) {
+        const float dr = d * c2_of(r);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) p[(size_t)r * pitch + 3 * x + 1] = fmaf(dr, c1_of(x), p[(size_t)r * pitch + 3 * x + 1]);
+    }
+}
+
+// DeShuffler.degenerate's epilogue on the device (de_shuffler.py:17-22) for a batch of frames:
+// mean of bits[i::L] from the counts, undo the key permutation, threshold strictly above the
+// mid-range of the L means.  One workgroup per frame; float64 like the reference.
+__global__ __launch_bounds__(kThreads) void degenerate_kernel(const int32_t *__restrict__ counts, int L, int n_bits,
+                                                              const int32_t *__restrict__ perm,
+                                                              uint8_t *__restrict__ payload) {
+    __shared__ double s_max[kThreads], s_min[kThreads];
+    __shared__ int s_nan[kThreads];
+    const int t = threadIdx.x;
+    const int f = blockIdx.x;
+    double mx = -1.0, mn = 2.0;      // means are in [0, 1]
+    int has_nan = 0;
+    for (int i = t; i < L; i += kThreads) {
+        const int len = i < n_bits ? (n_bits - i + L - 1) / L : 0;     // entries of bits[i::L]
+        if (len == 0) { has_nan = 1; continue; }                        // numpy: mean of empty slice = nan
+        const double m = (double)counts[(size_t)f * L + i] / (double)len;
+        mx = m > mx ? m : mx;
+        mn = m < mn ? m : mn;
+    }
+    s_max[t] = mx; s_min[t] = mn; s_nan[t] = has_nan;
+    __syncthreads();
+    for (int d = kThreads / 2; d > 0; d >>= 1) {
+        if (t < d) {
+            s_max[t] = s_max[t + d] > s_max[t] ? s_max[t + d] : s_max[t];
+            s_min[t] = s_min[t + d] < s_min[t] ? s_min[t + d] : s_min[t];
+            s_nan[t] |= s_nan[t + d];
+        }
+        __syncthreads();
+    }
+    const double thr = 0.5 * (s_max[0] + s_min[0]);
+    const bool poisoned = s_nan[0] != 0;                                // nan threshold: nothing compares greater
+    for (int i = t; i < L; i += kThreads) {
+        const int len = i < n_bits ? (n_bits - i + L - 1) / L : 0;
+        const double m = len ? (double)counts[(size_t)f * L + i] / (double)len : 0.0;
+        payload[(size_t)f * L + perm[i]] = (!poisoned && len && m > thr) ? 1 : 0;
     }
 }
 
@@ -492,17 +550,41 @@ __global__ void copy_fringe_kernel(const uint8_t *__restrict__ in, uint8_t *__re
     }
 }
 
+// Streaming copy, one 16-byte access per lane, each workgroup a contiguous 16 KiB span.
 __global__ __launch_bounds__(kThreads) void copy16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    const size_t base = (size_t)blockIdx.x * (kThreads * 4) + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k * kThreads < n16) v[k] = src[base + k * kThreads];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k * kThreads < n16) dst[base + k * kThreads] = v[k];
 }
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
-int g_analyze_tiles = 8;
-int g_apply_tiles = 8;
+int g_fuse_verify = 1;    // ofmk_embed_detect_rgb8: 1 = fused mark+analyze kernel, 0 = separate kernels
+
+// Optional per-launch HIP-event timing (bench.py): events are created by ofmk_timing_enable(),
+// recorded on the launch stream around every kernel, and read back by ofmk_timing_collect().
+enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_COUNT = 4 };
+struct TimingRec { hipEvent_t a, b; int kind; };
+TimingRec *g_trec = nullptr;
+int g_trec_cap = 0, g_trec_used = 0;
+
+struct ScopedTiming {      // records the "after" event when it goes out of scope
+    hipStream_t s;
+    TimingRec *r;
+    ScopedTiming(int kind, hipStream_t stream) : s(stream), r(nullptr) {
+        if (g_trec && g_trec_used < g_trec_cap) {
+            r = &g_trec[g_trec_used++];
+            r->kind = kind;
+            (void)hipEventRecord(r->a, s);
+        }
+    }
+    ~ScopedTiming() { if (r) (void)hipEventRecord(r->b, s); }
+};
 
 int fail(int code, const char *fmt, const char *detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
@@ -516,33 +598,37 @@ int fail(int code, const char *fmt, const char *detail = "") {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+constexpr int kMaxChunk = 65535;   // frames per launch = gridDim.y
+
 struct Workspace {
-    float *rec;
-    float *delta;
+    float *rec;      // 5 planes of [frames][nblk]
+    float *delta;    // [frames][nblk]
     unsigned long long *ysum;
-    int frames;   // chunk capacity
+    int frames;      // chunk capacity
+    size_t plane;    // frames * nblk
 };
 
 size_t per_frame_bytes(int H, int W) {
     const size_t nblk = (size_t)(H / 8) * (W / 8);
-    return align256(nblk * kRec * sizeof(float)) + align256(nblk * sizeof(float)) + align256(kSlots * 8);
+    return nblk * (kRec + 1) * sizeof(float) + kSlots * 8;
 }
 
 int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out) {
     if (!ws) return fail(OFMK_E_ARG, "workspace is null%s");
     if ((uintptr_t)ws % 256) return fail(OFMK_E_ARG, "workspace must be 256-byte aligned%s");
     const size_t per = per_frame_bytes(H, W);
-    size_t cap = bytes / per;
-    if (cap < 1) return fail(OFMK_E_WORKSPACE, "workspace smaller than ofmk_workspace_bytes(1, H, W)%s");
+    if (bytes < per + 1024) return fail(OFMK_E_WORKSPACE, "workspace smaller than ofmk_workspace_bytes(1, H, W)%s");
+    size_t cap = (bytes - 1024) / per;
     if (want_frames > 0 && (size_t)want_frames < cap) cap = want_frames;
-    if (cap > (1u << 20)) cap = 1u << 20;
+    if (cap > (size_t)kMaxChunk) cap = kMaxChunk;
     const size_t nblk = (size_t)(H / 8) * (W / 8);
     char *p = static_cast<char *>(ws);
     out.frames = (int)cap;
+    out.plane = cap * nblk;
     out.rec = reinterpret_cast<float *>(p);
-    p += align256(nblk * kRec * sizeof(float)) * cap;
+    p += align256(out.plane * kRec * sizeof(float));
     out.delta = reinterpret_cast<float *>(p);
-    p += align256(nblk * sizeof(float)) * cap;
+    p += align256(out.plane * sizeof(float));
     out.ysum = reinterpret_cast<unsigned long long *>(p);
     return OFMK_OK;
 }
@@ -550,22 +636,22 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
 int check_dims(int n, int H, int W) {
     if (n <= 0) return fail(OFMK_E_ARG, "n must be positive%s");
     if (H < 8 || W < 8) return fail(OFMK_E_ARG, "H and W must be at least 8%s");
-    if ((long long)H * W >= (1LL << 30)) return fail(OFMK_E_ARG, "frame too large (H*W must be < 2^30)%s");
+    if ((long long)H * W >= (1LL << 28)) return fail(OFMK_E_ARG, "frame too large (H*W must be < 2^28)%s");
     return OFMK_OK;
 }
 
-Geom make_geom(int n, int H, int W, int tiles_per_wg) {
+Geom make_geom(int H, int W, const Workspace &ws) {
     Geom g;
     g.W = W;
     g.wb = W / 8;
     g.inv_wb = 1.0f / (float)g.wb;
     g.nblk = (H / 8) * (W / 8);
-    g.tiles_per_frame = (g.nblk + kTileBlocks - 1) / kTileBlocks;
-    g.total_tiles = n * g.tiles_per_frame;
-    g.tiles_per_wg = tiles_per_wg;
     g.frame_stride = (size_t)H * W * 3;
+    g.plane = ws.plane;
     return g;
 }
+
+dim3 block_grid(const Geom &g, int n) { return dim3((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n); }
 
 bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block row starts on 8 B (u8) / 16 B (f32)
     const size_t need = elem == 1 ? 8 : 16;
@@ -574,15 +660,16 @@ bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block 
 
 int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)n * kSlots * 8, s));
-    const Geom g = make_geom(n, H, W, g_analyze_tiles);
-    const unsigned grid = (unsigned)((g.total_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg);
+    const Geom g = make_geom(H, W, ws);
+    const dim3 grid = block_grid(g, n);
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
+    ScopedTiming timing(KIND_ANALYZE, s);
     if (src == SRC_RGB8) {
-        if (al) hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, true>), dim3(grid), dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
-        else hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, false>), dim3(grid), dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
+        if (al) hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
+        else hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
     } else {
-        if (al) hipLaunchKernelGGL((analyze_kernel<SRC_YUV32F, true>), dim3(grid), dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
-        else hipLaunchKernelGGL((analyze_kernel<SRC_YUV32F, false>), dim3(grid), dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
+        if (al) hipLaunchKernelGGL((analyze_kernel<SRC_YUV32F, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
+        else hipLaunchKernelGGL((analyze_kernel<SRC_YUV32F, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
     }
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
@@ -590,17 +677,30 @@ int launch_analyze(const void *frames, int src, int n, int H, int W, const Works
 
 int launch_finalize(FinArgs a, int n, hipStream_t s) {
     const unsigned gx = (unsigned)((a.N + kThreads - 1) / kThreads);
+    ScopedTiming timing(KIND_FINALIZE, s);
     hipLaunchKernelGGL(finalize_kernel, dim3(gx, (unsigned)n), dim3(kThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
 
-int launch_apply_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const Workspace &ws, hipStream_t s) {
-    const Geom g = make_geom(n, H, W, g_apply_tiles);
-    const unsigned grid = (unsigned)((g.total_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg);
+// fused = true: also analyze the marked frames into ws.rec / ws.ysum (which finalize(embed) has
+// finished with by then -- same stream)
+int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const Workspace &ws, bool fused,
+                     hipStream_t s) {
+    if (fused) HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)n * kSlots * 8, s));
+    const Geom g = make_geom(H, W, ws);
+    const dim3 grid = block_grid(g, n);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
-    if (al) hipLaunchKernelGGL(apply_rgb8_kernel<true>, dim3(grid), dim3(kThreads), 0, s, in, out, g, ws.delta);
-    else hipLaunchKernelGGL(apply_rgb8_kernel<false>, dim3(grid), dim3(kThreads), 0, s, in, out, g, ws.delta);
+    {
+        ScopedTiming timing(fused ? KIND_MARK_FUSED : KIND_MARK, s);
+        if (fused) {
+            if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, true>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
+            else hipLaunchKernelGGL((mark_rgb8_kernel<false, true>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
+        } else {
+            if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
+            else hipLaunchKernelGGL((mark_rgb8_kernel<false, false>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
+        }
+    }
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
         hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
@@ -613,6 +713,7 @@ FinArgs fin_base(const Workspace &ws, int H, int W, double alpha) {
     FinArgs a;
     memset(&a, 0, sizeof(a));
     a.rec = ws.rec;
+    a.plane = ws.plane;
     a.ysum = ws.ysum;
     a.nblk = (H / 8) * (W / 8);
     a.N = (int)((long long)H * W / 64);
@@ -621,25 +722,40 @@ FinArgs fin_base(const Workspace &ws, int H, int W, double alpha) {
     return a;
 }
 
+int finalize_embed(int f0, int cf, int H, int W, const uint8_t *wm, const int32_t *wm_row, double alpha,
+                   const Workspace &ws, hipStream_t s) {
+    FinArgs a = fin_base(ws, H, W, alpha);
+    a.wm = wm;
+    a.wm_row = wm_row ? wm_row + f0 : nullptr;
+    a.delta = ws.delta;
+    return launch_finalize(a, cf, s);
+}
+
+int finalize_detect(int f0, int cf, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
+                    const Workspace &ws, hipStream_t s) {
+    FinArgs a = fin_base(ws, H, W, alpha);
+    a.L = L;
+    a.counts = counts ? counts + (size_t)f0 * L : nullptr;
+    a.bits = bits ? bits + (size_t)f0 * a.N : nullptr;
+    return launch_finalize(a, cf, s);
+}
+
+// analyze + finalize(embed) + mark for frames [f0, f0+cf); verify = also leave the marked frames'
+// records in the workspace (fused kernel), ready for finalize_detect
 int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W, const uint8_t *wm,
-                const int32_t *wm_row, double alpha, const Workspace &ws, hipStream_t s) {
+                const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, hipStream_t s) {
     const size_t fs = (size_t)H * W * 3;
     const size_t esz = src == SRC_RGB8 ? 1 : 4;
     const char *pin = static_cast<const char *>(in) + (size_t)f0 * fs * esz;
     char *pout = static_cast<char *>(out) + (size_t)f0 * fs * esz;
     int rc = launch_analyze(pin, src, cf, H, W, ws, s);
     if (rc) return rc;
-    FinArgs a = fin_base(ws, H, W, alpha);
-    a.wm = wm;
-    a.wm_row = wm_row ? wm_row + f0 : nullptr;
-    a.delta = ws.delta;
-    rc = launch_finalize(a, cf, s);
-    if (rc) return rc;
+    if ((rc = finalize_embed(f0, cf, H, W, wm, wm_row, alpha, ws, s))) return rc;
     if (src == SRC_RGB8)
-        return launch_apply_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, ws, s);
-    const Geom g = make_geom(cf, H, W, g_apply_tiles);
-    const unsigned grid = (unsigned)((g.total_tiles + g.tiles_per_wg - 1) / g.tiles_per_wg);
-    hipLaunchKernelGGL(apply_yuv32f_kernel, dim3(grid), dim3(kThreads), 0, s, reinterpret_cast<float *>(pout), g, ws.delta);
+        return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, ws,
+                                verify, s);
+    const Geom g = make_geom(H, W, ws);
+    hipLaunchKernelGGL(mark_yuv32f_kernel, block_grid(g, cf), dim3(kThreads), 0, s, reinterpret_cast<float *>(pout), g, ws.delta);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
@@ -651,11 +767,7 @@ int detect_chunk(const void *in, int src, int f0, int cf, int H, int W, int L, d
     const char *pin = static_cast<const char *>(in) + (size_t)f0 * fs * esz;
     int rc = launch_analyze(pin, src, cf, H, W, ws, s);
     if (rc) return rc;
-    FinArgs a = fin_base(ws, H, W, alpha);
-    a.L = L;
-    a.counts = counts ? counts + (size_t)f0 * L : nullptr;
-    a.bits = bits ? bits + (size_t)f0 * a.N : nullptr;
-    return launch_finalize(a, cf, s);
+    return finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, s);
 }
 
 int check_embed_args(const void *in, const void *out, int n, int H, int W, const uint8_t *wm, int n_wm) {
@@ -684,13 +796,10 @@ const char *ofmk_last_error(void) { return g_err; }
 
 size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W) {
     if (frames_in_flight < 1 || H < 8 || W < 8) return 0;
-    return per_frame_bytes(H, W) * (size_t)frames_in_flight;
+    return per_frame_bytes(H, W) * (size_t)frames_in_flight + 1024;
 }
 
-void ofmk_set_tiles_per_workgroup(int analyze_tiles, int apply_tiles) {
-    g_analyze_tiles = analyze_tiles > 0 ? analyze_tiles : 8;
-    g_apply_tiles = apply_tiles > 0 ? apply_tiles : 8;
-}
+void ofmk_set_fused_verify(int on) { g_fuse_verify = on ? 1 : 0; }
 
 int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                     const int32_t *wm_row, double alpha, int chunk_frames, void *workspace, size_t workspace_bytes,
@@ -702,7 +811,7 @@ int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, s))) return rc;
+        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
     }
     return OFMK_OK;
 }
@@ -734,8 +843,13 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
     if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, s))) return rc;
-        if ((rc = detect_chunk(out, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+        if (g_fuse_verify) {
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, s))) return rc;
+            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+        } else {
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
+            if ((rc = detect_chunk(out, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+        }
     }
     return OFMK_OK;
 }
@@ -749,7 +863,7 @@ int ofmk_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(yuv, yuv, SRC_YUV32F, f0, cf, H, W, wm, wm_row, alpha, ws, s))) return rc;
+        if ((rc = embed_chunk(yuv, yuv, SRC_YUV32F, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
     }
     return OFMK_OK;
 }
@@ -802,22 +916,69 @@ int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W, void *worksp
     return launch_analyze(in, SRC_RGB8, n, H, W, ws, static_cast<hipStream_t>(stream));
 }
 
-int ofmk_stage_apply_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, void *workspace,
-                          size_t workspace_bytes, void *stream) {
+int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int fused, void *workspace,
+                         size_t workspace_bytes, void *stream) {
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!in || !out) return fail(OFMK_E_ARG, "null frame pointer%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, n, ws))) return rc;
     if (ws.frames < n) return fail(OFMK_E_WORKSPACE, "stage call needs workspace for all n frames%s");
-    return launch_apply_rgb8(in, out, n, H, W, ws, static_cast<hipStream_t>(stream));
+    return launch_mark_rgb8(in, out, n, H, W, ws, fused != 0, static_cast<hipStream_t>(stream));
+}
+
+int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm, uint8_t *payload,
+                              void *stream) {
+    if (!counts || !perm || !payload) return fail(OFMK_E_ARG, "null pointer%s");
+    if (n < 1 || L < 1 || n_bits < 0) return fail(OFMK_E_ARG, "bad sizes%s");
+    hipLaunchKernelGGL(degenerate_kernel, dim3((unsigned)n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), counts,
+                       L, n_bits, perm, payload);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int ofmk_timing_enable(int max_launches) {
+    if (g_trec) return fail(OFMK_E_ARG, "timing already enabled%s");
+    if (max_launches < 1) return fail(OFMK_E_ARG, "max_launches must be positive%s");
+    g_trec = new TimingRec[max_launches];
+    for (int i = 0; i < max_launches; ++i) {
+        HIP_TRY(hipEventCreate(&g_trec[i].a));
+        HIP_TRY(hipEventCreate(&g_trec[i].b));
+    }
+    g_trec_cap = max_launches;
+    g_trec_used = 0;
+    return OFMK_OK;
+}
+
+int ofmk_timing_collect(double *ms_by_kind, int *launches_by_kind) {
+    if (!g_trec) return fail(OFMK_E_ARG, "timing is not enabled%s");
+    if (!ms_by_kind || !launches_by_kind) return fail(OFMK_E_ARG, "null output%s");
+    for (int k = 0; k < KIND_COUNT; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+    for (int i = 0; i < g_trec_used; ++i) {
+        HIP_TRY(hipEventSynchronize(g_trec[i].b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_trec[i].a, g_trec[i].b));
+        ms_by_kind[g_trec[i].kind] += ms;
+        launches_by_kind[g_trec[i].kind] += 1;
+    }
+    g_trec_used = 0;
+    return OFMK_OK;
+}
+
+void ofmk_timing_disable(void) {
+    if (!g_trec) return;
+    for (int i = 0; i < g_trec_cap; ++i) { (void)hipEventDestroy(g_trec[i].a); (void)hipEventDestroy(g_trec[i].b); }
+    delete[] g_trec;
+    g_trec = nullptr;
+    g_trec_cap = g_trec_used = 0;
 }
 
 int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream) {
     if (!src || !dst || bytes % 16 || (uintptr_t)src % 16 || (uintptr_t)dst % 16)
         return fail(OFMK_E_ARG, "copy needs 16-byte aligned pointers and size%s");
-    hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), bytes / 16);
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + kThreads * 4 - 1) / (kThreads * 4))), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }

@@ -16,7 +16,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "li
 SYMBOLS = (
     "ofmk_version", "ofmk_last_error", "ofmk_workspace_bytes", "ofmk_embed_rgb8", "ofmk_detect_rgb8",
     "ofmk_embed_detect_rgb8", "ofmk_encode_yuv32f", "ofmk_decode_yuv32f", "ofmk_debug_planes",
-    "ofmk_stage_analyze_rgb8", "ofmk_stage_apply_rgb8", "ofmk_hbm_copy", "ofmk_set_tiles_per_workgroup",
+    "ofmk_stage_analyze_rgb8", "ofmk_stage_mark_rgb8", "ofmk_hbm_copy", "ofmk_set_fused_verify",
+    "ofmk_timing_enable", "ofmk_timing_collect", "ofmk_timing_disable", "ofmk_payloads_from_counts",
 )
 
 
@@ -57,12 +58,20 @@ def load():
     lib.ofmk_decode_yuv32f.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, sz, vp]
     lib.ofmk_debug_planes.argtypes = [vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.ofmk_stage_analyze_rgb8.argtypes = [vp, i32, i32, i32, vp, sz, vp]
-    lib.ofmk_stage_apply_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, sz, vp]
+    lib.ofmk_stage_mark_rgb8.argtypes = [vp, vp, i32, i32, i32, i32, vp, sz, vp]
     lib.ofmk_hbm_copy.argtypes = [vp, vp, sz, vp]
-    lib.ofmk_set_tiles_per_workgroup.argtypes = [i32, i32]
-    lib.ofmk_set_tiles_per_workgroup.restype = None
+    lib.ofmk_set_fused_verify.argtypes = [i32]
+    lib.ofmk_set_fused_verify.restype = None
+    lib.ofmk_payloads_from_counts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.ofmk_payloads_from_counts.restype = i32
+    lib.ofmk_timing_enable.argtypes = [i32]
+    lib.ofmk_timing_enable.restype = i32
+    lib.ofmk_timing_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.ofmk_timing_collect.restype = i32
+    lib.ofmk_timing_disable.argtypes = []
+    lib.ofmk_timing_disable.restype = None
     for name in ("ofmk_embed_rgb8", "ofmk_detect_rgb8", "ofmk_embed_detect_rgb8", "ofmk_encode_yuv32f",
-                 "ofmk_decode_yuv32f", "ofmk_debug_planes", "ofmk_stage_analyze_rgb8", "ofmk_stage_apply_rgb8",
+                 "ofmk_decode_yuv32f", "ofmk_debug_planes", "ofmk_stage_analyze_rgb8", "ofmk_stage_mark_rgb8",
                  "ofmk_hbm_copy"):
         getattr(lib, name).restype = i32
     if lib.ofmk_version() != 1:

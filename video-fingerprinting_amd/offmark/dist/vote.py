@@ -1,0 +1,95 @@
+"""Frame/segment sharding across GPUs and the cross-frame payload vote.
+
+The reference has no parallelism (video/embedder.py:19-27 is one frame at a time); frames are
+independent, so each rank marks/reads its own contiguous shard and no frame ever crosses xGMI.
+The only exchange is the reference's cross-frame step: the per-frame recovered payloads are
+collected and the most common whole pattern wins (PatternCollectorExtractor,
+tests/segment_mark_detect_hls.py:126-155).  Here: one all-gather of [n_local, L] uint8 (RCCL when
+the backend is "nccl", gloo on CPU for tests), then the same Counter vote on every rank.
+"""
+from __future__ import annotations
+
+import os
+from collections import Counter
+
+import numpy as np
+
+
+def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous [start, stop) of ``rank``; the first n_total % world ranks get one extra item."""
+    base, extra = divmod(n_total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def init_from_env(backend: str | None = None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+    Returns (rank, world).  With WORLD_SIZE unset or 1 no group is created."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def payloads_from_counts(counts, n_bits: int, perm):
+    """Device-side DeShuffler epilogue (de_shuffler.py:17-22) for a batch: counts [n, L] (ones among
+    bits[i::L]) -> uint8 [n, L].  float64 like the reference; stays on ``counts``' device."""
+    import torch
+    L = counts.shape[-1]
+    i = torch.arange(L, device=counts.device)
+    lens = torch.where(i < n_bits, (n_bits - i + L - 1) // L, torch.zeros_like(i)).to(torch.float64)
+    means = counts.to(torch.float64) / lens
+    perm = torch.as_tensor(np.asarray(perm), device=counts.device, dtype=torch.long)
+    payload = torch.empty_like(means)
+    payload[..., perm] = means
+    thr = 0.5 * (payload.max(dim=-1, keepdim=True).values + payload.min(dim=-1, keepdim=True).values)
+    return (payload > thr).to(torch.uint8)
+
+
+def gather_payloads(local):
+    """all-gather per-frame payloads [n_local, L] uint8 -> [n_total, L] in rank order (ragged ok)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n_local = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * sizes[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def vote(patterns):
+    """Most common whole pattern and its frequency; ties go to the pattern seen first
+    (collections.Counter.most_common semantics, as the reference).  patterns: [n, L] of 0/1."""
+    rows = np.asarray(patterns)
+    if rows.ndim != 2 or rows.shape[0] == 0:
+        return None, None
+    rows = np.ascontiguousarray(rows.astype(np.uint8))
+    uniq, first, counts = np.unique(rows, axis=0, return_index=True, return_counts=True)
+    best = np.lexsort((first, -counts))[0]           # highest count, then earliest first appearance
+    return uniq[best].astype(np.int64), counts[best] / rows.shape[0]
+
+
+def vote_segments(patterns, segment_ids):
+    """Per-segment vote.  Returns {segment_id: (pattern, frequency)}."""
+    rows = np.asarray(patterns)
+    seg = np.asarray(segment_ids)
+    return {int(s): vote(rows[seg == s]) for s in np.unique(seg)}

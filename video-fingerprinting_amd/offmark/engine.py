@@ -12,9 +12,11 @@ import numpy as np
 
 from . import _hip
 
-# frames per internal chunk: a chunk's input (+ output) should stay inside the 256 MiB Infinity
-# Cache between the analyze pass and the apply pass (DESIGN.md "chunking").
-_CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 96 << 20))
+# Frames per internal chunk.  Measured on MI355X (profiles/): chunks small enough to stay in the
+# 256 MiB Infinity Cache between the analyze and apply passes do not pay -- the kernels are not
+# HBM-limited yet and short launches lose more to launch gaps and tails -- so the default is
+# large chunks (2 GiB of frames); OFFMARK_CHUNK_BYTES overrides (DESIGN.md "chunking").
+_CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 2 << 30))
 
 
 def default_chunk_frames(H: int, W: int) -> int:
@@ -124,6 +126,18 @@ class DctEngine:
                                                    counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
                                                    _hip.current_stream()))
         return out, counts, bits
+
+    def payloads(self, counts, n_bits: int, perm, out=None):
+        """Device epilogue of DeShuffler.degenerate for a batch: counts int32 [n, L] -> uint8 [n, L]."""
+        t = self.torch
+        n, L = counts.shape
+        if not isinstance(perm, t.Tensor):
+            perm = t.as_tensor(np.asarray(perm), dtype=t.int32).to(self.device)
+        if out is None:
+            out = t.empty((n, L), dtype=t.uint8, device=self.device)
+        _hip.check(self.lib.ofmk_payloads_from_counts(counts.data_ptr(), n, L, int(n_bits), perm.data_ptr(),
+                                                      out.data_ptr(), _hip.current_stream()))
+        return out
 
     # -- float32 YUV path (the literal encode(yuv)/decode(yuv) plugin boundary) ------------------
     def encode_yuv(self, yuv, wm, alpha=20, wm_row=None):
