@@ -259,3 +259,110 @@ def test_abi_error_codes(eng):
     assert lib.ofmk_workspace_bytes(0, 16, 16) == 0 and lib.ofmk_workspace_bytes(1, 16, 16) > 0
     with pytest.raises(_hip.HipError):
         _hip.check(-1)
+
+
+def test_fused_verify_kernel_equals_separate_kernels(eng):
+    """ofmk_embed_detect_rgb8: the fused mark+analyze kernel and the two separate kernels must agree
+    bit for bit (same arithmetic on the same rounded pixels)."""
+    import torch
+    from offmark import _hip
+    lib = _hip.load()
+    frames = cuda(np.stack([orc.synthetic_frame(240, 320, 1001 + i) for i in range(5)] ))
+    nat = np.load(os.path.join(GOLDEN, "frame63_crop_qr_k0_a20.npz"))["frame"]
+    wm = orc.shuffle_generate(P8, (1, 1200), 0)
+    try:
+        lib.ofmk_set_fused_verify(1)
+        o1, c1, b1 = eng.embed_detect(frames, wm, L=8, want_bits=True)
+        lib.ofmk_set_fused_verify(0)
+        o2, c2, b2 = eng.embed_detect(frames, wm, L=8, want_bits=True)
+    finally:
+        lib.ofmk_set_fused_verify(1)
+    assert torch.equal(o1, o2) and torch.equal(c1, c2) and torch.equal(b1, b2)
+    wmn = orc.shuffle_generate(P8, (1, nat.shape[0] * nat.shape[1] // 64), 0)
+    o3, c3, b3 = eng.embed_detect(cuda(nat[None]), wmn, L=8, want_bits=True)
+    c4, b4 = eng.detect(o3, 8, want_bits=True)
+    assert torch.equal(c3, c4) and torch.equal(b3, b4)
+
+
+def test_device_payload_epilogue_equals_host(eng):
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    rng = np.random.default_rng(9)
+    for (L, N, key) in [(8, 32400, 0), (5, 37, 7), (441, 1536, 0), (13, 6, 3), (300, 32400, 1)]:
+        deg = DeShuffler(key=key).set_shape((L,))
+        lens = np.array([max(0, (N - i + L - 1) // L) if i < N else 0 for i in range(L)])
+        counts = (rng.random((17, L)) * (lens + 0.999)).astype(np.int32)
+        counts = np.minimum(counts, lens).astype(np.int32)
+        with np.errstate(all="ignore"):
+            ref = deg.degenerate_counts(counts, N)
+        got = eng.payloads(torch.from_numpy(counts).cuda(), N, deg.payload_idx).cpu().numpy()
+        assert np.array_equal(got, ref), (L, N)
+
+
+def test_config1_pipeline_on_gpu_209_frames(eng):
+    """mark.py / detect.py logic on an in-memory stand-in for the bundled 320x240, 209-frame clip."""
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.embed.dct_encoder import DctEncoder
+    from offmark.extract.dct_decoder import DctDecoder
+    from offmark.generator.shuffler import Shuffler
+    from offmark.video.embedder import Embedder
+    from offmark.video.extractor import Extractor
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark.video.frame_writer import ArrayFrameWriter
+    base = [orc.synthetic_frame(240, 320, 1001 + i) for i in range(11)]
+    frames = np.stack([np.roll(base[i % 11], 8 * (i // 11), axis=1) for i in range(209)])
+    r, w = ArrayFrameReader(frames), ArrayFrameWriter()
+    frame_embedder = DctEncoder()
+    capacity = frame_embedder.wm_capacity((r.height, r.width, 3))
+    frame_embedder.read_wm(Shuffler(key=0).generate_wm(P8, capacity))
+    emb = Embedder(r, frame_embedder, w, batch_frames=50)
+    emb.start()
+    assert emb.frames_marked == 209 and len(w.frames) == 209 and r.closed and w.closed
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(Shuffler(key=0).generate_wm(P8, capacity))
+    for i in (0, 57, 208):
+        mask, _ = sign_determined_pixels(frames[i], frame_embedder.wm[None], 20)
+        assert_pixels_close(w.frames[i], orc.mark_frame(frames[i], enc), mask)
+    ex = Extractor(ArrayFrameReader(w.frames), DctDecoder(), DeShuffler(key=0).set_shape(P8.shape), batch_frames=64)
+    ex.start()
+    assert len(ex.patterns) == 209 and all(np.array_equal(p, P8) for p in ex.patterns)
+    assert np.array_equal(ex.most_common()[0], P8)
+
+
+def test_4k_frame_against_oracle(eng):
+    H, W = 2160, 3840
+    frame = orc.synthetic_frame(H, W, 3001)
+    wm = orc.shuffle_generate(P8, (1, H * W // 64), 0)
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(wm)
+    ref_marked = orc.mark_frame(frame, enc)
+    marked, counts, bits = eng.embed_detect(cuda(frame[None]), wm, L=8, want_bits=True)
+    mask = np.ones((H, W), bool)
+    ok = np.abs(enc.debug["c21_pre"]) > C21_TOL
+    mask[:] = np.kron(ok, np.ones((8, 8), bool))
+    assert_pixels_close(marked[0].cpu().numpy(), ref_marked, mask)
+    ref_bits = orc.check_frame(ref_marked, orc.DctDecoderOracle(alpha=20))
+    _, b2 = eng.detect(cuda(ref_marked[None]), 8, want_bits=True)
+    assert_bits_close(b2[0].cpu().numpy(), ref_bits, 129600)
+    from offmark.degenerator.de_shuffler import DeShuffler
+    assert np.array_equal(DeShuffler(key=0).set_shape((8,)).degenerate_counts(counts[0].cpu().numpy(), 129600), P8)
+
+
+def test_stage_entry_points_and_copy(eng):
+    import torch
+    from offmark import _hip
+    lib = _hip.load()
+    frames = cuda(np.stack([orc.synthetic_frame(64, 96, 5 + i) for i in range(3)]))
+    wm = orc.shuffle_generate(P8, (1, 96), 0)
+    ref = eng.embed(frames, wm)                      # leaves this batch's deltas in the workspace
+    ws = eng.workspace(64, 96, 3)
+    out = torch.empty_like(frames)
+    s = _hip.current_stream()
+    _hip.check(lib.ofmk_stage_analyze_rgb8(frames.data_ptr(), 3, 64, 96, ws.data_ptr(), ws.numel(), s))
+    _hip.check(lib.ofmk_stage_mark_rgb8(frames.data_ptr(), out.data_ptr(), 3, 64, 96, 0, ws.data_ptr(), ws.numel(), s))
+    assert torch.equal(out, ref)
+    a = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+    b = torch.zeros_like(a)
+    _hip.check(lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), a.numel() * 4, s))
+    assert torch.equal(a, b)
+    assert lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), 7, s) == -1

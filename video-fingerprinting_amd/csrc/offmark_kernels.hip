@@ -93,12 +93,6 @@ __device__ __forceinline__ void dct8(float (&x)[8]) {
 __device__ __forceinline__ float proj1(const float (&v)[8]) {
     return fmaf(v[3] - v[4], H7, fmaf(v[2] - v[5], H5, fmaf(v[1] - v[6], H3, (v[0] - v[7]) * H1)));
 }
-// coefficient 2 of the 8-point DCT only, same association as dct8's x[2]
-__device__ __forceinline__ float proj2(const float (&v)[8]) {
-    const float a0 = v[0] + v[7], a1 = v[1] + v[6], a2 = v[2] + v[5], a3 = v[3] + v[4];
-    return fmaf(a1 - a2, H6, (a0 - a3) * H2);
-}
-
 __device__ __forceinline__ void divmod_small(int c, int d, float inv_d, int &q, int &r) {
     q = (int)((float)c * inv_d);       // c < 2^24 is checked on the host
     r = c - q * d;
@@ -184,7 +178,14 @@ struct BlockFeat { float a00, tot, dcl, e, c21; };
 // R[r][k]: row-DCT outputs of the Y block (row r, horizontal frequency k); u1[r]: k=1 projection
 // of the U rows.  Column DCTs in place, then the texture-mask features with the reference's own
 // association order (dct_encoder.py:80-86; np.sum = 8 running column sums combined pairwise).
-__device__ __forceinline__ BlockFeat block_features(float (&R)[8][8], const float (&u1)[8]) {
+// u1[r] for r < 4 first holds row r's projection; when row 7-r arrives it becomes
+// a_r = p[r] + p[7-r], the first butterfly stage of the 8-point DCT's coefficient 2
+// (same association as dct8 / the oracle, so a vertically symmetric U gives an exact zero).
+__device__ __forceinline__ void fold_u1(float (&u1)[4], int r, float p) {
+    if (r < 4) u1[r] = p; else u1[7 - r] += p;
+}
+
+__device__ __forceinline__ BlockFeat block_features(float (&R)[8][8], const float (&u1)[4]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float col[8];
@@ -211,7 +212,7 @@ __device__ __forceinline__ BlockFeat block_features(float (&R)[8][8], const floa
     ft.dcl = ((((R[0][0] + R[0][1]) + R[0][2]) + R[1][0]) + R[1][1]) + R[2][0];
     ft.e = ((((((((((R[3][0] + R[4][0]) + R[5][0]) + R[6][0]) + R[0][3]) + R[0][4]) + R[0][5]) + R[0][6]) +
               R[2][1]) + R[1][2]) + R[2][2]) + R[3][3];
-    ft.c21 = proj2(u1);
+    ft.c21 = fmaf(u1[1] - u1[2], H6, (u1[0] - u1[3]) * H2);   // u1[] holds the folded sums a_r (see fold_u1)
     return ft;
 }
 
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kThreads, OFMK_ANALYZE_WAVES) void analyze_kernel(c
     divmod_small(valid ? c : g.nblk - 1, g.wb, g.inv_wb, bi, bj);     // ragged tail recomputes the last block
     const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
     const int pitch = g.W * 3;
-    float R[8][8], u1[8];
+    float R[8][8], u1[4];
     if constexpr (SRC == SRC_RGB8) {
         const uint8_t *p = static_cast<const uint8_t *>(frames) + off;
         // rolling prefetch: OFMK_PREFETCH_ROWS rows of raw bytes in flight, each row consumed (colour
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kThreads, OFMK_ANALYZE_WAVES) void analyze_kernel(c
                 raw[r + OFMK_PREFETCH_ROWS] = load_px8<ALIGNED>(p + (size_t)(r + OFMK_PREFETCH_ROWS) * pitch);
             float y[8], u[8];
             row_yu(raw[r], y, u);
-            u1[r] = proj1(u);
+            fold_u1(u1, r, proj1(u));
             dct8(y);
 #pragma unroll
             for (int k = 0; k < 8; ++k) R[r][k] = y[k];
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kThreads, OFMK_ANALYZE_WAVES) void analyze_kernel(c
 #pragma unroll
                 for (int x = 0; x < 8; ++x) { y[x] = q[3 * x]; u[x] = q[3 * x + 1]; }
             }
-            u1[r] = proj1(u);
+            fold_u1(u1, r, proj1(u));
             dct8(y);
 #pragma unroll
             for (int k = 0; k < 8; ++k) R[r][k] = y[k];
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_r
     Px8 raw[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) raw[r] = load_px8<ALIGNED>(in + off + (size_t)r * pitch);
-    float R[8][8], u1[8];
+    float R[8][8], u1[4];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const Px8 &px = raw[r];
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_r
         if constexpr (FUSED) {
             float y[8], u[8];
             row_yu(o, y, u);           // what detect will see: the rounded, clipped u8 pixels
-            u1[r] = proj1(u);
+            fold_u1(u1, r, proj1(u));
             dct8(y);
 #pragma unroll
             for (int k = 0; k < 8; ++k) R[r][k] = y[k];
@@ -572,12 +573,13 @@ enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, 
 struct TimingRec { hipEvent_t a, b; int kind; };
 TimingRec *g_trec = nullptr;
 int g_trec_cap = 0, g_trec_used = 0;
+unsigned g_trec_mask = 0xF;     // which kernel kinds get bracketed
 
 struct ScopedTiming {      // records the "after" event when it goes out of scope
     hipStream_t s;
     TimingRec *r;
     ScopedTiming(int kind, hipStream_t stream) : s(stream), r(nullptr) {
-        if (g_trec && g_trec_used < g_trec_cap) {
+        if (g_trec && ((g_trec_mask >> kind) & 1u) && g_trec_used < g_trec_cap) {
             r = &g_trec[g_trec_used++];
             r->kind = kind;
             (void)hipEventRecord(r->a, s);
@@ -937,8 +939,9 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
     return OFMK_OK;
 }
 
-int ofmk_timing_enable(int max_launches) {
+int ofmk_timing_enable(int max_launches, unsigned kind_mask) {
     if (g_trec) return fail(OFMK_E_ARG, "timing already enabled%s");
+    g_trec_mask = kind_mask ? kind_mask : 0xF;
     if (max_launches < 1) return fail(OFMK_E_ARG, "max_launches must be positive%s");
     g_trec = new TimingRec[max_launches];
     for (int i = 0; i < max_launches; ++i) {

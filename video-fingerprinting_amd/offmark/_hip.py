@@ -64,7 +64,7 @@ def load():
     lib.ofmk_set_fused_verify.restype = None
     lib.ofmk_payloads_from_counts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.ofmk_payloads_from_counts.restype = i32
-    lib.ofmk_timing_enable.argtypes = [i32]
+    lib.ofmk_timing_enable.argtypes = [i32, C.c_uint]
     lib.ofmk_timing_enable.restype = i32
     lib.ofmk_timing_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.ofmk_timing_collect.restype = i32
