@@ -9,11 +9,11 @@
 //   src/offmark/degenerator/de_shuffler.py:17-18  sums of bits[i::L] (the mean's numerator)
 //
 // Kernels (DESIGN.md has the full story):
-//   analyze  : frame pixels -> 5 floats per 8x8 block {A00, sum|A|, dcl, e, C21} + a fixed-point
+//   analyze  : frame pixels -> 3 floats per 8x8 block {A00, texture-mask code, C21} + a fixed-point
 //              sum of the block DCs (the luminance mask needs the frame-global mean first).
-//              Shared by embed and detect.  Reads 3 B/px, writes 0.31 B/px.
-//   finalize : one thread per block: luminance/texture masks (float64 like the reference), step,
-//              then either the QIM delta of C21 (embed) or the read-out bit + bits[i::L] counts.
+//              Shared by embed and detect.  Reads 3 B/px, writes 0.19 B/px.
+//   finalize : one thread per block: luminance mask (float64 like the reference), step, then
+//              either the QIM delta of C21 (embed) or the read-out bit + bits[i::L] counts.
 //   mark     : frame pixels + delta -> marked pixels.  The 8x8 DCT is orthonormal, so
 //              idct(dct(U) + d*e21) == U + d * outer(c2, c1): a rank-1 update, no DCT needed.
 //              The FUSED variant also analyzes the marked block it has just produced (mark +
@@ -37,7 +37,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kRec = 5;           // float planes per block record: A00, sum|A|, dcl, e, C21
+constexpr int kRec = 3;           // float planes per block record: A00, texture code, C21
 constexpr int kSlots = 32;        // fixed-point mean accumulators per frame (spreads atomics)
 constexpr int kHistMax = 2048;    // payload lengths up to this use an LDS histogram in finalize
 
@@ -173,7 +173,38 @@ struct Geom {
     size_t plane;         // elements between record planes (frames in flight * nblk)
 };
 
-struct BlockFeat { float a00, tot, dcl, e, c21; };
+struct BlockFeat { float a00, tex, c21; };
+
+// texture_mask (dct_encoder.py:70-102) as a one-float code: 1, 1.125 or 1.25 stand for themselves
+// (exact in float32); a negative value -eh means "the ramp 1 + 1.25*(eh - 290)/1510", which
+// finalize evaluates in float64 from the float32 eh, as numpy 1.23 does (eh > 125 there, so the
+// sign is unambiguous).  float32 arithmetic exactly where the reference's numpy scalars are
+// float32; comparisons with python floats are float64 because the reference pins numpy 1.23
+// (legacy promotion: np.float32 scalar (op) python scalar -> float64).  l/e and (l+e)/h may be
+// inf or nan; IEEE comparisons with nan are false, as in the reference.
+__device__ __forceinline__ float texture_code(float a00abs, float tot, float dcl, float e) {
+    // branch-free: everything is computed, the decision tree becomes selects (no control flow in
+    // the middle of a register-heavy kernel)
+    const float eh = tot - dcl;
+    const float h = eh - e;
+    const float l = dcl - a00abs;
+    const float l_e = l / e;
+    const float lpe = l + e;
+    const float le_h = lpe / h;
+    const bool active = eh > 125.f;
+    const bool big = eh > 900.f;
+    const double a = big ? 1.4 : 2.3, b = big ? 1.1 : 1.6;
+    const double dl_e = (double)l_e, dle_h = (double)le_h;
+    const bool cond = (dl_e >= a && dle_h >= b) || (dl_e >= b && dle_h >= a) || (le_h > 4.f);
+    const bool ramp = big || (e + h > 290.f);
+    const float stepped = lpe <= 400.f ? 1.125f : 1.25f;
+    const float inner = cond ? stepped : (ramp ? -eh : 1.0f);
+    return active ? inner : 1.0f;
+}
+__device__ __forceinline__ double texture_value(float code) {
+    return code > 0.f ? (double)code : 1.0 + 1.25 * ((double)(-code) - 290.0) / 1510.0;
+}
+
 
 // R[r][k]: row-DCT outputs of the Y block (row r, horizontal frequency k); u1[r]: k=1 projection
 // of the U rows.  Column DCTs in place, then the texture-mask features with the reference's own
@@ -182,41 +213,54 @@ struct BlockFeat { float a00, tot, dcl, e, c21; };
 // a_r = p[r] + p[7-r], the first butterfly stage of the 8-point DCT's coefficient 2
 // (same association as dct8 / the oracle, so a vertically symmetric U gives an exact zero).
 __device__ __forceinline__ void fold_u1(float (&u1)[4], int r, float p) {
+    // Opaque use: C21 is only stored under `if (valid)` at the very end, and without this LLVM sinks
+    // the whole U chain (64 pixels' c0 and Y) down into that branch -- 300 bytes of spills per lane.
+    asm volatile("" : "+v"(p));
     if (r < 4) u1[r] = p; else u1[7 - r] += p;
 }
 
 __device__ __forceinline__ BlockFeat block_features(float (&R)[8][8], const float (&u1)[4]) {
+    // One column at a time: DCT it, fold |coefficients| into numpy's 8 running sums (np.sum of the
+    // contiguous 8x8 block keeps one accumulator per column j and adds the rows in order), pick the
+    // 18 coefficients dcl and e need, and let the column die.  The scheduling barrier pins this order;
+    // without it the compiler interleaves all eight columns and spills.
+    float rs[8], A[4][4], A0[8], Ai0[8];     // A[i][j] for i,j < 4; A0[j] = |A[0][j]|; Ai0[i] = |A[i][0]|
+    BlockFeat ft;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float col[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) col[i] = R[i][j];
         dct8(col);
+        if (j == 0) ft.a00 = col[0];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) R[i][j] = col[i];
+        for (int i = 0; i < 8; ++i) col[i] = fabsf(col[i]);
+        rs[j] = col[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) rs[j] += col[i];
+        A0[j] = col[0];
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Ai0[i] = col[i];
+        }
+        if (j < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[i][j] = col[i];
+        }
+#if OFMK_ROW_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
-    BlockFeat ft;
-    ft.a00 = R[0][0];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) R[i][j] = fabsf(R[i][j]);
-    float rs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        rs[j] = R[0][j];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) rs[j] += R[i][j];
-    }
-    ft.tot = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
-    ft.dcl = ((((R[0][0] + R[0][1]) + R[0][2]) + R[1][0]) + R[1][1]) + R[2][0];
-    ft.e = ((((((((((R[3][0] + R[4][0]) + R[5][0]) + R[6][0]) + R[0][3]) + R[0][4]) + R[0][5]) + R[0][6]) +
-              R[2][1]) + R[1][2]) + R[2][2]) + R[3][3];
+    const float tot = ((rs[0] + rs[1]) + (rs[2] + rs[3])) + ((rs[4] + rs[5]) + (rs[6] + rs[7]));
+    const float dcl = ((((A[0][0] + A[0][1]) + A[0][2]) + A[1][0]) + A[1][1]) + A[2][0];
+    const float e = ((((((((((Ai0[3] + Ai0[4]) + Ai0[5]) + Ai0[6]) + A0[3]) + A0[4]) + A0[5]) + A0[6]) +
+                     A[2][1]) + A[1][2]) + A[2][2]) + A[3][3];
+    ft.tex = texture_code(A[0][0], tot, dcl, e);
     ft.c21 = fmaf(u1[1] - u1[2], H6, (u1[0] - u1[3]) * H2);   // u1[] holds the folded sums a_r (see fold_u1)
     return ft;
 }
 
-// Records are five planes of [frames][nblk] floats; the frame's block DCs also go, as 2^19 fixed
+// Records are three planes of [frames][nblk] floats; the frame's block DCs also go, as 2^19 fixed
 // point, into one of kSlots 64-bit accumulators: integer adds commute, so the frame mean is
 // bit-reproducible however the workgroups are scheduled.
 __device__ __forceinline__ void emit_block(const BlockFeat &ft, bool valid, int f, int c, const Geom &g,
@@ -224,10 +268,8 @@ __device__ __forceinline__ void emit_block(const BlockFeat &ft, bool valid, int 
     if (valid) {
         float *r = rec + (size_t)f * g.nblk + c;
         r[0] = ft.a00;
-        r[g.plane] = ft.tot;
-        r[2 * g.plane] = ft.dcl;
-        r[3 * g.plane] = ft.e;
-        r[4 * g.plane] = ft.c21;
+        r[g.plane] = ft.tex;
+        r[2 * g.plane] = ft.c21;
     }
     const int q = valid ? __float2int_rn(ft.a00 * 524288.0f) : 0;     // A00 * 2^19, |A00| <= 2040
     const int lo = wave_sum(q & 0xffff), hi = wave_sum(q >> 16);
@@ -307,7 +349,7 @@ __global__ __launch_bounds__(kThreads, OFMK_ANALYZE_WAVES) void analyze_kernel(c
 // finalize
 // ------------------------------------------------------------------------------------------
 struct FinArgs {
-    const float *rec;                 // 5 planes of [frames][nblk]
+    const float *rec;                 // 3 planes of [frames][nblk]: A00, texture code, C21
     size_t plane;
     const unsigned long long *ysum;   // [frames][kSlots]
     int nblk, N, L;
@@ -321,30 +363,6 @@ struct FinArgs {
     double *lum, *tex, *step;
     float *c21_pre, *c21_post;
 };
-
-// texture_mask, dct_encoder.py:70-102.  float32 arithmetic exactly where the reference's numpy
-// scalars are float32; the comparisons with python floats and the ramp are float64 because the
-// reference pins numpy 1.23 (legacy promotion: np.float32 scalar (op) python scalar -> float64).
-__device__ __forceinline__ double texture_mask(float a00abs, float tot, float dcl, float e) {
-    const float eh = tot - dcl;
-    double out = 1.0;
-    if (eh > 125.f) {
-        const float h = eh - e;
-        const float l = dcl - a00abs;
-        const float l_e = l / e;
-        const float lpe = l + e;
-        const float le_h = lpe / h;
-        const bool big = eh > 900.f;
-        const double a = big ? 1.4 : 2.3, b = big ? 1.1 : 1.6;
-        const double dl_e = (double)l_e, dle_h = (double)le_h;
-        const bool cond = (dl_e >= a && dle_h >= b) || (dl_e >= b && dle_h >= a) || (le_h > 4.f);
-        const double ramp = 1.0 + 1.25 * ((double)eh - 290.0) / 1510.0;
-        if (cond) out = lpe <= 400.f ? 1.125 : 1.25;
-        else if (big) out = ramp;
-        else if (e + h > 290.f) out = ramp;
-    }
-    return out;
-}
 
 __global__ __launch_bounds__(kThreads) void finalize_kernel(FinArgs p) {
     __shared__ int hist[kHistMax];
@@ -367,14 +385,14 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(FinArgs p) {
         const double mean = s_mean > 90.0 ? s_mean : 90.0;
         const double f_ref = 1.0 + (mean - 90.0) * 1.0 / 165.0;
         const float *r = p.rec + (size_t)f * p.nblk + c;
-        const float a00 = r[0], tot = r[p.plane], dcl = r[2 * p.plane], e = r[3 * p.plane], c21 = r[4 * p.plane];
+        const float a00 = r[0], tcode = r[p.plane], c21 = r[2 * p.plane];
         const double m = (double)a00 / 8.0;
         double lum;
         if (m > mean) lum = 1.0 + (m - mean) / (255.0 - mean) * (2.0 - f_ref);
         else if (m < 15.0) lum = 1.25;
         else if (m < 25.0) lum = 1.125;
         else lum = 1.0;
-        const double tex = texture_mask(fabsf(a00), tot, dcl, e);
+        const double tex = texture_value(tcode);
         const double step = p.alpha * (tex * lum);
         const size_t o = (size_t)f * p.nblk + c;
         if (p.y_dc) p.y_dc[o] = a00;
@@ -603,7 +621,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxChunk = 65535;   // frames per launch = gridDim.y
 
 struct Workspace {
-    float *rec;      // 5 planes of [frames][nblk]
+    float *rec;      // kRec planes of [frames][nblk]
     float *delta;    // [frames][nblk]
     unsigned long long *ysum;
     int frames;      // chunk capacity
