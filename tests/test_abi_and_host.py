@@ -185,3 +185,21 @@ def test_payloads_from_counts_torch_matches_degenerate_counts():
         ref = deg.degenerate_counts(counts, N)
         got = payloads_from_counts(torch.from_numpy(counts), N, deg.payload_idx).numpy()
         assert np.array_equal(got, ref)
+
+
+def test_fingerprint_bookkeeping():
+    from offmark import fingerprint as fp
+    assert fp.payload_for_segment(5).tolist() == [0, 0, 0, 0, 0, 1, 0, 1]
+    assert fp.payload_for_segment(261).tolist() == fp.payload_for_segment(5).tolist()      # wraps at 256
+    assert fp.payload_for_segment(3, 2).tolist() == [0, 0, 1, 1, 0, 0, 1, 0]
+    assert fp.payload_for_segment(19, 18).tolist() == fp.payload_for_segment(3, 2).tolist()  # both wrap at 16
+    assert fp.decode_pattern(np.array([0, 0, 1, 1, 0, 0, 1, 0])) == (3, 2)
+    assert fp.decode_pattern([1, 0, 1]) == (None, None) and fp.decode_pattern(None) == (None, None)
+    assert fp.select_copies("01201201", 8, 3) == [0, 1, 2, 0, 1, 2, 0, 1]
+    assert fp.select_copies("57", 2, 3) == [2, 1]
+    with pytest.raises(ValueError):
+        fp.select_copies("01", 3, 3)
+    assert fp.view_to_copies(5, 3, 4) == [0, 0, 1, 2] and fp.view_to_copies(0, 3, 2) == [0, 0]
+    votes = {0: (fp.payload_for_segment(0, 1), 1.0), 1: (fp.payload_for_segment(1, 2), 0.9),
+             2: (fp.payload_for_segment(7, 0), 0.8)}                                         # segment 2 decodes as 7: reject
+    assert fp.identify_copies(votes) == [1, 2, None]

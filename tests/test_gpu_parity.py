@@ -366,3 +366,66 @@ def test_stage_entry_points_and_copy(eng):
     _hip.check(lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), a.numel() * 4, s))
     assert torch.equal(a, b)
     assert lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), 7, s) == -1
+
+
+def test_config4_segments_with_own_payloads(eng):
+    """BASELINE config 4 shape on one GPU: 8 segments x 48 frames of 1080p, segment s carries
+    format(s % 256, '08b') (segment_mark_detect_hls.py:42-55); per-segment Counter vote must return it."""
+    import torch
+    from offmark import fingerprint as fp
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.dist.vote import vote_segments
+    from offmark.synthetic import synthetic_frames
+    H, W, S, F = 1080, 1920, 8, 48
+    N = H * W // 64
+    frames = synthetic_frames(S * F, H, W, seed=4000)
+    payloads = np.stack([fp.payload_for_segment(s + 1) for s in range(S)])
+    wm = np.stack([orc.shuffle_generate(p, (N,), 0) for p in payloads])
+    seg = np.repeat(np.arange(S), F)
+    _, counts, _ = eng.embed_detect(frames, wm, L=8, wm_row=seg.astype(np.int32))
+    deg = DeShuffler(key=0).set_shape((8,))
+    per_frame = eng.payloads(counts, N, deg.payload_idx).cpu().numpy()
+    assert np.array_equal(per_frame, deg.degenerate_counts(counts.cpu().numpy(), N))
+    votes = vote_segments(per_frame, seg)
+    for s in range(S):
+        assert np.array_equal(votes[s][0], payloads[s]) and votes[s][1] == 1.0
+
+
+def test_config5_leak_identification_with_build_defined_attacks(eng):
+    """BASELINE config 5 shape: 8 segments x 3 copies, payload = segment(4b)||copy(4b)
+    (mark_video_to_hls.py:38-43); a leak picks one copy per segment (generate_leak.py:59-108) and the
+    detector must return the copy sequence (detect_watermarks.py:345-364).  The reference has no
+    attacks; the ones here are build-defined tensor ops.  Only 'none' and 'requantisation noise' are
+    gated; scaling and cropping break the 8x8 grid and are merely reported."""
+    import torch
+    from offmark import fingerprint as fp
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.dist.vote import vote_segments
+    from offmark.synthetic import synthetic_frames
+    H, W, S, C, F = 240, 320, 8, 3, 12
+    N = H * W // 64
+    src = synthetic_frames(S * F, H, W, seed=5000)
+    deg = DeShuffler(key=0).set_shape((8,))
+    wm_table = np.stack([orc.shuffle_generate(fp.payload_for_segment(s, c), (N,), 0) for s in range(S) for c in range(C)])
+    seg = np.repeat(np.arange(S), F)
+    copies = [eng.embed(src, wm_table, wm_row=(seg * C + c).astype(np.int32)) for c in range(C)]
+    leak_pattern = "01201201"
+    chosen = fp.select_copies(leak_pattern, S, C)
+    leak = torch.cat([copies[chosen[s]][s * F:(s + 1) * F] for s in range(S)])
+
+    def identify(frames):
+        counts, _ = eng.detect(frames.contiguous(), 8)
+        votes = vote_segments(eng.payloads(counts, N, deg.payload_idx).cpu().numpy(), seg)
+        return fp.identify_copies(votes)
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    noisy = (leak.float() + 2.0 * torch.randn(leak.shape, device="cuda", generator=g)).round().clamp(0, 255).to(torch.uint8)
+    assert identify(leak) == chosen
+    assert identify(noisy) == chosen
+    x = leak.permute(0, 3, 1, 2).float()
+    small = torch.nn.functional.interpolate(x, size=(H * 2 // 3, W * 2 // 3), mode="bilinear", align_corners=False)
+    scaled = torch.nn.functional.interpolate(small, size=(H, W), mode="bilinear", align_corners=False)
+    cropped = torch.nn.functional.interpolate(x[:, :, 16:-16, 16:-16], size=(H, W), mode="bilinear", align_corners=False)
+    for name, t in (("scale 2/3", scaled), ("crop 16", cropped)):
+        got = identify(t.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1))
+        print(f"attack {name}: recovered {sum(a == b for a, b in zip(got, chosen))}/{S} copies (not gated)")
