@@ -107,11 +107,13 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
 
 /* ---- individual stages (bench.py and tests drive single kernels with these) ----------------
  * analyze : frames -> per-block records (the kernel shared by embed and detect)
- * mark    : frames + the per-block coefficient deltas left in the workspace by the last embed ->
- *           marked frames; fused != 0 also analyzes the marked frames (mark + verify kernel)   */
+ * mark    : frames + the records the analyze stage left in the workspace for the SAME frames +
+ *           watermark (row 0 for every frame) -> marked frames; fused != 0 also analyzes the
+ *           marked frames (mark + verify kernel)                                             */
 int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W,
                             void *workspace, size_t workspace_bytes, void *stream);
-int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int fused,
+int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
+                         const uint8_t *wm, double alpha, int fused,
                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Device-to-device streaming copy with 16-byte accesses; bench.py uses it to measure the

@@ -354,12 +354,14 @@ def test_stage_entry_points_and_copy(eng):
     lib = _hip.load()
     frames = cuda(np.stack([orc.synthetic_frame(64, 96, 5 + i) for i in range(3)]))
     wm = orc.shuffle_generate(P8, (1, 96), 0)
-    ref = eng.embed(frames, wm)                      # leaves this batch's deltas in the workspace
+    ref = eng.embed(frames, wm)
     ws = eng.workspace(64, 96, 3)
     out = torch.empty_like(frames)
     s = _hip.current_stream()
+    wm_dev = cuda(wm.astype(np.uint8))
     _hip.check(lib.ofmk_stage_analyze_rgb8(frames.data_ptr(), 3, 64, 96, ws.data_ptr(), ws.numel(), s))
-    _hip.check(lib.ofmk_stage_mark_rgb8(frames.data_ptr(), out.data_ptr(), 3, 64, 96, 0, ws.data_ptr(), ws.numel(), s))
+    _hip.check(lib.ofmk_stage_mark_rgb8(frames.data_ptr(), out.data_ptr(), 3, 64, 96, wm_dev.data_ptr(), 20.0, 0,
+                                        ws.data_ptr(), ws.numel(), s))
     assert torch.equal(out, ref)
     a = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
     b = torch.zeros_like(a)

@@ -281,6 +281,42 @@ __device__ __forceinline__ void emit_block(const BlockFeat &ft, bool valid, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// per-block scalar stage shared by finalize and mark (float64 like the reference)
+// ------------------------------------------------------------------------------------------
+// Frame-global mean of the block means A00/8 (luminance_mask, dct_encoder.py:54-56) from the
+// fixed-point accumulators; the first wavefront leaves it in LDS.  Caller adds the barrier.
+__device__ __forceinline__ void frame_mean_to_lds(const unsigned long long *__restrict__ ysum, int f, int nblk,
+                                                  double *s_mean) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        long long s = t < kSlots ? (long long)ysum[(size_t)f * kSlots + t] : 0;
+#pragma unroll
+        for (int d = 1; d < kSlots; d <<= 1) s += __shfl_xor(s, d);
+        if (t == 0) *s_mean = ((double)s * (1.0 / 4194304.0)) / (double)nblk;   // sum(A00 * 2^19) -> mean(A00 / 8)
+    }
+}
+
+// luminance_mask's per-block branch (dct_encoder.py:57-66) for block mean m = A00/8
+__device__ __forceinline__ double luminance_value(float a00, double mean_m) {
+    const double mean = mean_m > 90.0 ? mean_m : 90.0;
+    const double f_ref = 1.0 + (mean - 90.0) * 1.0 / 165.0;
+    const double m = (double)a00 / 8.0;
+    if (m > mean) return 1.0 + (m - mean) / (255.0 - mean) * (2.0 - f_ref);
+    if (m < 15.0) return 1.25;
+    if (m < 25.0) return 1.125;
+    return 1.0;
+}
+
+// QIM, dct_encoder.py:30-35 (float64 on a float32 coefficient; np.sign(0) == 0 keeps a zero at zero)
+__device__ __forceinline__ float qim_new_coeff(float c21, double step, int bit) {
+    const double step2 = step + step;
+    double q = floor(fabs((double)c21) / step2) * step2;
+    if (bit) q = q + step;
+    const double nv = c21 > 0.f ? q : (c21 < 0.f ? -q : 0.0);
+    return (float)nv;
+}
+
+// ------------------------------------------------------------------------------------------
 // analyze
 // ------------------------------------------------------------------------------------------
 template <int SRC, bool ALIGNED>
@@ -373,25 +409,12 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(FinArgs p) {
     const bool use_hist = p.counts != nullptr && p.L <= kHistMax;
     if (use_hist)
         for (int k = t; k < p.L; k += kThreads) hist[k] = 0;
-    if (t < 64) {
-        // frame-global mean of the block means (luminance_mask, dct_encoder.py:54-56)
-        long long s = t < kSlots ? (long long)p.ysum[(size_t)f * kSlots + t] : 0;
-#pragma unroll
-        for (int d = 1; d < kSlots; d <<= 1) s += __shfl_xor(s, d);
-        if (t == 0) s_mean = ((double)s * (1.0 / 4194304.0)) / (double)p.nblk;   // sum(A00 * 2^19) -> mean(A00 / 8)
-    }
+    frame_mean_to_lds(p.ysum, f, p.nblk, &s_mean);
     __syncthreads();
     if (c < p.nblk) {
-        const double mean = s_mean > 90.0 ? s_mean : 90.0;
-        const double f_ref = 1.0 + (mean - 90.0) * 1.0 / 165.0;
         const float *r = p.rec + (size_t)f * p.nblk + c;
         const float a00 = r[0], tcode = r[p.plane], c21 = r[2 * p.plane];
-        const double m = (double)a00 / 8.0;
-        double lum;
-        if (m > mean) lum = 1.0 + (m - mean) / (255.0 - mean) * (2.0 - f_ref);
-        else if (m < 15.0) lum = 1.25;
-        else if (m < 25.0) lum = 1.125;
-        else lum = 1.0;
+        const double lum = luminance_value(a00, s_mean);
         const double tex = texture_value(tcode);
         const double step = p.alpha * (tex * lum);
         const size_t o = (size_t)f * p.nblk + c;
@@ -402,14 +425,8 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(FinArgs p) {
         if (p.c21_pre) p.c21_pre[o] = c21;
 
         if (p.delta || p.c21_post) {
-            // QIM, dct_encoder.py:30-35 (float64 on a float32 coefficient; sign(0) = 0)
             const int row = p.wm_row ? p.wm_row[f] : 0;
-            const int bit = p.wm[(size_t)row * p.N + c];
-            const double step2 = step + step;
-            double q = floor(fabs((double)c21) / step2) * step2;
-            if (bit) q = q + step;
-            const double nv = c21 > 0.f ? q : (c21 < 0.f ? -q : 0.0);
-            const float newc = (float)nv;
+            const float newc = qim_new_coeff(c21, step, p.wm[(size_t)row * p.N + c]);
             if (p.c21_post) p.c21_post[o] = newc;
             if (p.delta) p.delta[o] = newc - c21;
         }
@@ -445,24 +462,45 @@ __device__ __forceinline__ uint32_t put_u8(float v, int sel, uint32_t word) {
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, word);
 }
 
-// embedder.py:33-39 for one block per thread.  FUSED: also analyze the marked block (detect's
-// front end on the frame being written), producing its records and mean accumulator.
+struct MarkArgs {
+    const float *rec;                 // records of the INPUT frames (from analyze)
+    const unsigned long long *ysum;   // their mean accumulators
+    const uint8_t *wm;                // [n_wm][N]
+    const int32_t *wm_row;            // [frames] or null
+    int N;
+    double alpha;
+};
+
+// embedder.py:33-39 for one block per thread, including the per-block scalar stage (masks -> step ->
+// QIM of C21, dct_encoder.py:21-35) that turns the input frame's record into this block's delta.
+// FUSED: also analyze the marked block (detect's front end on the frame being written), producing
+// its records (rec_out may alias m.rec: a thread reads its own entries before it overwrites them)
+// and mean accumulator (ysum_out, a different buffer from m.ysum).
 template <bool ALIGNED, bool FUSED>
 __global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_rgb8_kernel(const uint8_t *__restrict__ in,
-                                                             uint8_t *__restrict__ out, Geom g,
-                                                             const float *__restrict__ delta,
-                                                             float *__restrict__ rec,
-                                                             unsigned long long *__restrict__ ysum) {
+                                                             uint8_t *__restrict__ out, Geom g, MarkArgs m,
+                                                             float *rec_out,
+                                                             unsigned long long *__restrict__ ysum_out) {
+    __shared__ double s_mean;
     const int f = blockIdx.y;
     const int c = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = c < g.nblk;
+    frame_mean_to_lds(m.ysum, f, g.nblk, &s_mean);
+    __syncthreads();
     if (!FUSED && !valid) return;
     const int cc = valid ? c : g.nblk - 1;
+    float d;
+    {
+        const float *r = m.rec + (size_t)f * g.nblk + cc;
+        const float a00 = r[0], tcode = r[g.plane], c21 = r[2 * g.plane];
+        const double step = m.alpha * (texture_value(tcode) * luminance_value(a00, s_mean));
+        const int row = m.wm_row ? m.wm_row[f] : 0;
+        d = qim_new_coeff(c21, step, m.wm[(size_t)row * m.N + cc]) - c21;
+    }
     int bi, bj;
     divmod_small(cc, g.wb, g.inv_wb, bi, bj);
     const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
     const int pitch = g.W * 3;
-    const float d = delta[(size_t)f * g.nblk + cc];
     Px8 raw[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) raw[r] = load_px8<ALIGNED>(in + off + (size_t)r * pitch);
@@ -495,7 +533,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_r
     }
     if constexpr (FUSED) {
         const BlockFeat ft = block_features(R, u1);
-        emit_block(ft, valid, f, c, g, rec, ysum);
+        emit_block(ft, valid, f, c, g, rec_out, ysum_out);
     }
 }
 
@@ -623,14 +661,15 @@ constexpr int kMaxChunk = 65535;   // frames per launch = gridDim.y
 struct Workspace {
     float *rec;      // kRec planes of [frames][nblk]
     float *delta;    // [frames][nblk]
-    unsigned long long *ysum;
+    unsigned long long *ysum;    // mean accumulators of the frames analyze() saw
+    unsigned long long *ysum2;   // ... of the marked frames (fused mark+verify kernel)
     int frames;      // chunk capacity
     size_t plane;    // frames * nblk
 };
 
 size_t per_frame_bytes(int H, int W) {
     const size_t nblk = (size_t)(H / 8) * (W / 8);
-    return nblk * (kRec + 1) * sizeof(float) + kSlots * 8;
+    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8;
 }
 
 int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out) {
@@ -650,6 +689,8 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     out.delta = reinterpret_cast<float *>(p);
     p += align256(out.plane * sizeof(float));
     out.ysum = reinterpret_cast<unsigned long long *>(p);
+    p += align256(cap * kSlots * 8);
+    out.ysum2 = reinterpret_cast<unsigned long long *>(p);
     return OFMK_OK;
 }
 
@@ -703,22 +744,29 @@ int launch_finalize(FinArgs a, int n, hipStream_t s) {
     return OFMK_OK;
 }
 
-// fused = true: also analyze the marked frames into ws.rec / ws.ysum (which finalize(embed) has
-// finished with by then -- same stream)
-int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const Workspace &ws, bool fused,
-                     hipStream_t s) {
-    if (fused) HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)n * kSlots * 8, s));
+// Needs the input frames' records in ws.rec / ws.ysum (launch_analyze).  fused = true also leaves the
+// MARKED frames' records in ws.rec and their mean accumulators in ws.ysum2.
+int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
+                     double alpha, const Workspace &ws, bool fused, hipStream_t s) {
+    if (fused) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws);
     const dim3 grid = block_grid(g, n);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
+    MarkArgs m;
+    m.rec = ws.rec;
+    m.ysum = ws.ysum;
+    m.wm = wm;
+    m.wm_row = wm_row;
+    m.N = (int)((long long)H * W / 64);
+    m.alpha = alpha;
     {
         ScopedTiming timing(fused ? KIND_MARK_FUSED : KIND_MARK, s);
         if (fused) {
-            if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, true>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
-            else hipLaunchKernelGGL((mark_rgb8_kernel<false, true>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
+            if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
+            else hipLaunchKernelGGL((mark_rgb8_kernel<false, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
         } else {
-            if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
-            else hipLaunchKernelGGL((mark_rgb8_kernel<false, false>), grid, dim3(kThreads), 0, s, in, out, g, ws.delta, ws.rec, ws.ysum);
+            if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
+            else hipLaunchKernelGGL((mark_rgb8_kernel<false, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -742,26 +790,18 @@ FinArgs fin_base(const Workspace &ws, int H, int W, double alpha) {
     return a;
 }
 
-int finalize_embed(int f0, int cf, int H, int W, const uint8_t *wm, const int32_t *wm_row, double alpha,
-                   const Workspace &ws, hipStream_t s) {
-    FinArgs a = fin_base(ws, H, W, alpha);
-    a.wm = wm;
-    a.wm_row = wm_row ? wm_row + f0 : nullptr;
-    a.delta = ws.delta;
-    return launch_finalize(a, cf, s);
-}
-
 int finalize_detect(int f0, int cf, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
-                    const Workspace &ws, hipStream_t s) {
+                    const Workspace &ws, bool after_fused_mark, hipStream_t s) {
     FinArgs a = fin_base(ws, H, W, alpha);
+    if (after_fused_mark) a.ysum = ws.ysum2;
     a.L = L;
     a.counts = counts ? counts + (size_t)f0 * L : nullptr;
     a.bits = bits ? bits + (size_t)f0 * a.N : nullptr;
     return launch_finalize(a, cf, s);
 }
 
-// analyze + finalize(embed) + mark for frames [f0, f0+cf); verify = also leave the marked frames'
-// records in the workspace (fused kernel), ready for finalize_detect
+// analyze + mark for frames [f0, f0+cf); verify = also leave the marked frames' records in the
+// workspace (fused kernel), ready for finalize_detect(after_fused_mark = true)
 int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W, const uint8_t *wm,
                 const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, hipStream_t s) {
     const size_t fs = (size_t)H * W * 3;
@@ -770,10 +810,16 @@ int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W
     char *pout = static_cast<char *>(out) + (size_t)f0 * fs * esz;
     int rc = launch_analyze(pin, src, cf, H, W, ws, s);
     if (rc) return rc;
-    if ((rc = finalize_embed(f0, cf, H, W, wm, wm_row, alpha, ws, s))) return rc;
+    const int32_t *rows = wm_row ? wm_row + f0 : nullptr;
     if (src == SRC_RGB8)
-        return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, ws,
-                                verify, s);
+        return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, wm,
+                                rows, alpha, ws, verify, s);
+    // float32 YUV plugin path: separate scalar stage, then the rank-1 update of channel 1
+    FinArgs a = fin_base(ws, H, W, alpha);
+    a.wm = wm;
+    a.wm_row = rows;
+    a.delta = ws.delta;
+    if ((rc = launch_finalize(a, cf, s))) return rc;
     const Geom g = make_geom(H, W, ws);
     hipLaunchKernelGGL(mark_yuv32f_kernel, block_grid(g, cf), dim3(kThreads), 0, s, reinterpret_cast<float *>(pout), g, ws.delta);
     HIP_TRY(hipGetLastError());
@@ -787,7 +833,7 @@ int detect_chunk(const void *in, int src, int f0, int cf, int H, int W, int L, d
     const char *pin = static_cast<const char *>(in) + (size_t)f0 * fs * esz;
     int rc = launch_analyze(pin, src, cf, H, W, ws, s);
     if (rc) return rc;
-    return finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, s);
+    return finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, false, s);
 }
 
 int check_embed_args(const void *in, const void *out, int n, int H, int W, const uint8_t *wm, int n_wm) {
@@ -865,7 +911,7 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         if (g_fuse_verify) {
             if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, s))) return rc;
-            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
         } else {
             if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
             if ((rc = detect_chunk(out, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
@@ -936,15 +982,14 @@ int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W, void *worksp
     return launch_analyze(in, SRC_RGB8, n, H, W, ws, static_cast<hipStream_t>(stream));
 }
 
-int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int fused, void *workspace,
-                         size_t workspace_bytes, void *stream) {
-    int rc = check_dims(n, H, W);
+int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, double alpha,
+                         int fused, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_embed_args(in, out, n, H, W, wm, 1);
     if (rc) return rc;
-    if (!in || !out) return fail(OFMK_E_ARG, "null frame pointer%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, n, ws))) return rc;
     if (ws.frames < n) return fail(OFMK_E_WORKSPACE, "stage call needs workspace for all n frames%s");
-    return launch_mark_rgb8(in, out, n, H, W, ws, fused != 0, static_cast<hipStream_t>(stream));
+    return launch_mark_rgb8(in, out, n, H, W, wm, nullptr, alpha, ws, fused != 0, static_cast<hipStream_t>(stream));
 }
 
 int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm, uint8_t *payload,

@@ -58,7 +58,7 @@ def load():
     lib.ofmk_decode_yuv32f.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, sz, vp]
     lib.ofmk_debug_planes.argtypes = [vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.ofmk_stage_analyze_rgb8.argtypes = [vp, i32, i32, i32, vp, sz, vp]
-    lib.ofmk_stage_mark_rgb8.argtypes = [vp, vp, i32, i32, i32, i32, vp, sz, vp]
+    lib.ofmk_stage_mark_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, f64, i32, vp, sz, vp]
     lib.ofmk_hbm_copy.argtypes = [vp, vp, sz, vp]
     lib.ofmk_set_fused_verify.argtypes = [i32]
     lib.ofmk_set_fused_verify.restype = None
