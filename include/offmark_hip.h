@@ -77,6 +77,24 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                            int L, int32_t *counts, uint8_t *bits,
                            int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- DwtDctSvd codec (what tests/mark.py and tests/detect.py construct) -----------------------
+ * src/offmark/embed/dwt_dct_svd_encoder.py:19-45 (Haar LL of channel 1 -> 4x4 blocks -> DCT -> SVD ->
+ * s[0] = (s[0] // scale + 0.25 + 0.5*bit) * scale -> back) and
+ * src/offmark/extract/dwt_dct_svd_decoder.py:12-37 (bit = (s[0] % scale) > scale/2), for the
+ * reference's default scales=[0, scale, 0], blk=4.  Same frame/watermark/counts/bits conventions as
+ * the DCT entry points; no workspace (this codec has no frame-global dependency: one pass).     */
+int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
+                        const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream);
+int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double scale,
+                         int32_t *counts, uint8_t *bits, void *stream);
+int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
+                               const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale,
+                               int L, int32_t *counts, uint8_t *bits, void *stream);
+/* plugin level, float32 YUV [n][H][W][3] (n <= 65535): encode mutates channel 1; decode fills bits */
+int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W,
+                           const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream);
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, double scale, uint8_t *bits, void *stream);
+
 /* ---- DeShuffler.degenerate's epilogue for a batch, on the device ---------------------------
  * src/offmark/degenerator/de_shuffler.py:17-22: mean of bits[i::L] (from `counts`), undo the key
  * permutation (`perm` = DeShuffler.payload_idx, device int32 [L]), threshold strictly above the
@@ -124,9 +142,9 @@ int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream);
  * enabled every launch of a kernel kind selected in kind_mask (bit k = kind k, 0 = all) is
  * bracketed by hipEventRecord on the launch stream; collect()
  * waits for the recorded events, returns the summed milliseconds and launch counts per kernel
- * kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze) and rewinds the pool.  Not for use under graph capture. */
+ * kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze, 4 DwtDctSvd) and rewinds the pool.  Not for use under graph capture. */
 int ofmk_timing_enable(int max_launches, unsigned kind_mask);
-int ofmk_timing_collect(double *ms_by_kind /*[4]*/, int *launches_by_kind /*[4]*/);
+int ofmk_timing_collect(double *ms_by_kind /*[5]*/, int *launches_by_kind /*[5]*/);
 void ofmk_timing_disable(void);
 
 /* Process-wide switch for ofmk_embed_detect_rgb8: 1 (default) marks and analyzes the marked block

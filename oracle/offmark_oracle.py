@@ -140,6 +140,71 @@ def idct8x8(coeffs: np.ndarray) -> np.ndarray:
     return t.astype(F32)
 
 
+def _dct4_last(x: np.ndarray, inverse: bool = False) -> np.ndarray:
+    """Orthonormal 4-point DCT-II (or its inverse) along the last axis, float64, butterfly form."""
+    c1, c3, h = math.cos(math.pi / 8), math.cos(3 * math.pi / 8), 0.5
+    r = math.sqrt(0.5)
+    out = np.empty_like(x)
+    if not inverse:
+        a0, a1 = x[..., 0] + x[..., 3], x[..., 1] + x[..., 2]
+        b0, b1 = x[..., 0] - x[..., 3], x[..., 1] - x[..., 2]
+        out[..., 0] = (a0 + a1) * h
+        out[..., 2] = (a0 - a1) * h
+        out[..., 1] = r * (b0 * c1 + b1 * c3)
+        out[..., 3] = r * (b0 * c3 - b1 * c1)
+    else:
+        e0, e1 = (x[..., 0] + x[..., 2]) * h, (x[..., 0] - x[..., 2]) * h
+        o0 = r * (x[..., 1] * c1 + x[..., 3] * c3)
+        o1 = r * (x[..., 1] * c3 - x[..., 3] * c1)
+        out[..., 0], out[..., 3] = e0 + o0, e0 - o0
+        out[..., 1], out[..., 2] = e1 + o1, e1 - o1
+    return out
+
+
+def dct4x4(blocks: np.ndarray) -> np.ndarray:
+    """``cv2.dct`` on a 4x4 float32 block (dwt_dct_svd_encoder.py:43, dwt_dct_svd_decoder.py:34)."""
+    x = np.asarray(blocks, dtype=F32).astype(F64)
+    t = _dct4_last(x)
+    return np.swapaxes(_dct4_last(np.swapaxes(t, -1, -2)), -1, -2).astype(F32)
+
+
+def idct4x4(coeffs: np.ndarray) -> np.ndarray:
+    """``cv2.idct`` on a 4x4 float32 block (dwt_dct_svd_encoder.py:45)."""
+    x = np.asarray(coeffs, dtype=F32).astype(F64)
+    t = _dct4_last(x, inverse=True)
+    return np.swapaxes(_dct4_last(np.swapaxes(t, -1, -2), inverse=True), -1, -2).astype(F32)
+
+
+_HAAR = F32(0.7071067811865476)      # pywt's haar filter taps, in the data's precision (float32)
+
+
+def haar_dwt2(x: np.ndarray):
+    """``pywt.dwt2(x, 'haar')`` stand-in for even-sized float32 input: (cA, (cH, cV, cD)).
+    One-level orthonormal Haar, axis -2 first then axis -1, float32 arithmetic like PyWavelets'
+    float32 kernels.  PyWavelets is not installed: its arithmetic is PARITY UNPINNED."""
+    x = np.asarray(x, dtype=F32)
+    lo = x[..., 0::2, :] * _HAAR + x[..., 1::2, :] * _HAAR
+    hi = x[..., 0::2, :] * _HAAR - x[..., 1::2, :] * _HAAR
+    ca = lo[..., :, 0::2] * _HAAR + lo[..., :, 1::2] * _HAAR
+    cv = lo[..., :, 0::2] * _HAAR - lo[..., :, 1::2] * _HAAR
+    ch = hi[..., :, 0::2] * _HAAR + hi[..., :, 1::2] * _HAAR
+    cd = hi[..., :, 0::2] * _HAAR - hi[..., :, 1::2] * _HAAR
+    return ca, (ch, cv, cd)
+
+
+def haar_idwt2(coeffs) -> np.ndarray:
+    """``pywt.idwt2((cA, (cH, cV, cD)), 'haar')`` stand-in (inverse of haar_dwt2)."""
+    ca, (ch, cv, cd) = coeffs
+    ca, ch, cv, cd = (np.asarray(a, dtype=F32) for a in (ca, ch, cv, cd))
+    lo = np.empty(ca.shape[:-1] + (ca.shape[-1] * 2,), F32)
+    hi = np.empty_like(lo)
+    lo[..., 0::2], lo[..., 1::2] = ca * _HAAR + cv * _HAAR, ca * _HAAR - cv * _HAAR
+    hi[..., 0::2], hi[..., 1::2] = ch * _HAAR + cd * _HAAR, ch * _HAAR - cd * _HAAR
+    out = np.empty(lo.shape[:-2] + (lo.shape[-2] * 2, lo.shape[-1]), F32)
+    out[..., 0::2, :], out[..., 1::2, :] = lo * _HAAR + hi * _HAAR, lo * _HAAR - hi * _HAAR
+    return out
+
+
 # OpenCV float "YUV" constants (color_yuv: B2Y, G2Y, R2Y, B2U-style 0.492, R2V-style 0.877)
 _C_Y = (F32(0.114), F32(0.587), F32(0.299))
 _C_U = F32(0.492)
@@ -485,6 +550,90 @@ class DctDecoderOracle:
             wm[: rows * cols] = qim_read(c21, self.alpha * mask).reshape(-1)
             self.debug = dict(mask=mask, lum=lum, tex=tex, c21=c21, ydc=ycoef[..., 0, 0])
         return np.array(wm).reshape(1, -1)
+
+
+# --------------------------------------------------------------------------------------
+# (f)-1  DwtDctSvd codec (embed/dwt_dct_svd_encoder.py:5-45, extract/dwt_dct_svd_decoder.py:5-37)
+# --------------------------------------------------------------------------------------
+
+def to_blocks4(plane: np.ndarray) -> np.ndarray:
+    h4, w4 = plane.shape[0] // 4, plane.shape[1] // 4
+    return np.ascontiguousarray(plane[: h4 * 4, : w4 * 4].reshape(h4, 4, w4, 4).transpose(0, 2, 1, 3))
+
+
+class DwtDctSvdEncoderOracle:
+    """Haar LL band of channel 1 -> 4x4 blocks -> DCT -> SVD -> quantise the top singular value.
+    ``np.linalg.svd`` on float32 runs LAPACK in float32, here as in the reference."""
+
+    def __init__(self, key=None, scales=(0, 15, 0), blk=4, form: str = "vec"):
+        self.key, self.scales, self.blk, self.form = key, list(scales), blk, form
+        self.debug: dict = {}
+
+    def read_wm(self, wm):
+        self.wm = wm[0]
+
+    def wm_capacity(self, frame_shape):
+        row, col, _ = frame_shape
+        return (1, row * col // 64)
+
+    def encode(self, yuv):
+        row, col, _ = yuv.shape
+        for channel in range(3):
+            scale = self.scales[channel]
+            if scale <= 0:
+                continue
+            ca, hvd = haar_dwt2(yuv[: row // 4 * 4, : col // 4 * 4, channel])
+            ca = np.array(ca)
+            rows, cols = ca.shape[0] // self.blk, ca.shape[1] // self.blk
+            if self.form == "loop":
+                c = 0
+                for i in range(rows):
+                    for j in range(cols):
+                        blk = ca[i * 4:i * 4 + 4, j * 4:j * 4 + 4]
+                        u, s, v = np.linalg.svd(dct4x4(blk))
+                        s[0] = (s[0] // scale + 0.25 + 0.5 * self.wm[c]) * scale
+                        ca[i * 4:i * 4 + 4, j * 4:j * 4 + 4] = idct4x4(np.dot(u, np.dot(np.diag(s), v)))
+                        c += 1
+            else:
+                blocks = to_blocks4(ca)
+                u, s, v = np.linalg.svd(dct4x4(blocks))
+                s0 = s[..., 0].copy()
+                bits = np.asarray(self.wm)[: rows * cols].reshape(rows, cols)
+                s[..., 0] = ((s[..., 0] // scale + 0.25 + 0.5 * bits) * scale).astype(F32)
+                new = idct4x4(np.matmul(u, s[..., :, None] * v))
+                ca[: rows * 4, : cols * 4] = new.transpose(0, 2, 1, 3).reshape(rows * 4, cols * 4)
+                self.debug = dict(s0=s0, s0_new=s[..., 0].copy(), gap=(s[..., 1] / np.maximum(s0, 1e-30)))
+            yuv[: row // 4 * 4, : col // 4 * 4, channel] = haar_idwt2((ca, hvd))
+        return yuv
+
+
+class DwtDctSvdDecoderOracle:
+    def __init__(self, key=None, scales=(0, 15, 0), blk=4, form: str = "vec"):
+        self.key, self.scales, self.blk, self.form = key, list(scales), blk, form
+        self.debug: dict = {}
+
+    def decode(self, yuv):
+        row, col, _ = yuv.shape
+        n = row * col // 4 // (self.blk * self.blk)
+        wm_bits = np.zeros(shape=(3, n))
+        for channel in range(3):
+            scale = self.scales[channel]
+            if scale <= 0:
+                continue
+            ca, _ = haar_dwt2(yuv[: row // 4 * 4, : col // 4 * 4, channel])
+            rows, cols = ca.shape[0] // self.blk, ca.shape[1] // self.blk
+            if self.form == "loop":
+                c = 0
+                for i in range(rows):
+                    for j in range(cols):
+                        _, s, _ = np.linalg.svd(dct4x4(ca[i * 4:i * 4 + 4, j * 4:j * 4 + 4]))
+                        wm_bits[channel][c] = int((s[0] % scale) > scale * 0.5)
+                        c += 1
+            else:
+                s = np.linalg.svd(dct4x4(to_blocks4(ca)), compute_uv=False)
+                wm_bits[channel][: rows * cols] = ((s[..., 0] % scale) > scale * 0.5).reshape(-1)
+                self.debug = dict(s0=s[..., 0])
+        return np.array(wm_bits[1]).reshape(1, -1)
 
 
 # --------------------------------------------------------------------------------------

@@ -39,4 +39,11 @@ def golden_dir():
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "payload_codecs.npz")
+    """DCT codec cases."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith(".npz") and f != "payload_codecs.npz" and not f.startswith("svd_"))
+
+
+def svd_golden_cases():
+    """DwtDctSvd codec cases."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("svd_") and f.endswith(".npz"))

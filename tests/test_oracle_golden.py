@@ -138,3 +138,38 @@ def test_vote_is_counter_mode():
     best, freq = orc.vote(pats)
     assert best.tolist() == [0, 1] and abs(freq - 2 / 3) < 1e-12
     assert orc.vote([]) == (None, None)
+
+
+# ---- DwtDctSvd codec: oracle vs vectors from the reference's own modules -------------
+from conftest import svd_golden_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("form", ["vec", "loop"])
+@pytest.mark.parametrize("case", svd_golden_cases())
+def test_svd_codec_bit_exact_against_reference(case, form):
+    g = load(case)
+    if form == "loop" and g["frame"].shape[0] > 128:
+        pytest.skip("loop form only on small frames")
+    enc = orc.DwtDctSvdEncoderOracle(form=form)
+    wm = orc.shuffle_generate(g["payload"], (1, g["frame"].shape[0] * g["frame"].shape[1] // 64), int(g["key"]))
+    assert np.array_equal(wm, g["wm"])
+    enc.read_wm(wm)
+    if "yuv_in" in g.files:
+        assert np.array_equal(enc.encode(g["yuv_in"].copy()), g["yuv_out"])
+    assert np.array_equal(orc.mark_frame(g["frame"], enc), g["marked"])
+    dec = orc.DwtDctSvdDecoderOracle(form=form)
+    raw = orc.check_frame(g["marked"], dec)
+    assert raw.shape == g["raw_bits"].shape and np.array_equal(raw, g["raw_bits"])
+    assert np.array_equal(orc.deshuffle(raw, g["payload"].size, int(g["key"])), g["degenerated"])
+
+
+def test_haar_and_dct4_primitives():
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-100, 100, size=(16, 24)).astype(np.float32)
+    ca, hvd = orc.haar_dwt2(x)
+    assert ca.shape == (8, 12) and np.allclose(ca, (x[0::2, 0::2] + x[0::2, 1::2] + x[1::2, 0::2] + x[1::2, 1::2]) / 2, atol=1e-4)
+    assert np.allclose(orc.haar_idwt2((ca, hvd)), x, atol=1e-4)
+    b = rng.uniform(-50, 50, size=(10, 4, 4)).astype(np.float32)
+    c = orc.dct4x4(b)
+    assert np.allclose(orc.idct4x4(c), b, atol=1e-4)
+    assert np.allclose(np.linalg.svd(c, compute_uv=False), np.linalg.svd(b, compute_uv=False), rtol=1e-5)   # DCT is orthonormal

@@ -4,7 +4,7 @@ Run in the build container only (needs /root/reference):  python tools/make_gold
 
 * numpy-only reference modules (shuffler, grayscale, de_shuffler, de_grayscale) are imported
   and run as they are -> fully pinned vectors.
-* dct_encoder / dct_decoder / video.embedder import ``cv2``; tools/cv2_standin supplies
+* dct_encoder / dct_decoder / video.embedder import ``cv2``; tools/standins supplies
   dct / idct / cvtColor from the oracle primitives (OpenCV arithmetic itself unpinned).
 The reference's text is never copied: only inputs and outputs are stored.
 The container's numpy is 2.x, so the captured texture-mask values follow NEP 50 promotion
@@ -19,7 +19,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "cv2_standin"))
+sys.path.insert(0, os.path.join(HERE, "standins"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, "/root/reference/src")
 
@@ -33,6 +33,8 @@ from offmark.extract.dct_decoder import DctDecoder  # noqa: E402
 from offmark.generator.grayscale import GrayScale  # noqa: E402
 from offmark.generator.shuffler import Shuffler  # noqa: E402
 from offmark.video.embedder import Embedder  # noqa: E402
+from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder  # noqa: E402  (needs the pywt + cv2 stand-ins)
+from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -76,8 +78,34 @@ def run_case(name, frame, payload, key, alpha, image_payload=False, store_yuv=Fa
           f"raw_ber={np.mean(raw_bits.reshape(-1)[:wm.size] != wm.reshape(-1)):.4f} payload_ok={ok}")
 
 
+def run_svd_case(name, frame, payload, key, store_yuv=False):
+    """mark.py / detect.py's codec pair (DwtDctSvdEncoder / DwtDctSvdDecoder) on one frame."""
+    h, w, _ = frame.shape
+    enc, dec = DwtDctSvdEncoder(), DwtDctSvdDecoder()
+    wm = Shuffler(key=key).generate_wm(payload, enc.wm_capacity((h, w, 3)))
+    enc.read_wm(wm)
+    deg = DeShuffler(key=key).set_shape(payload.shape)
+    yuv_in = cv2.cvtColor(frame.astype(np.float32), cv2.COLOR_BGR2YUV)
+    yuv_out = enc.encode(yuv_in.copy())
+    marked = Embedder(None, enc, None)._Embedder__mark_frame(frame)
+    raw_bits = dec.decode(cv2.cvtColor(marked.astype(np.float32), cv2.COLOR_BGR2YUV))
+    d = dict(frame=frame, payload=np.asarray(payload), key=np.int64(key), wm=wm, marked=marked, raw_bits=raw_bits,
+             raw_bits_clean=dec.decode(yuv_out.copy()), degenerated=deg.degenerate(raw_bits))
+    if store_yuv:
+        d.update(yuv_in=yuv_in, yuv_out=yuv_out)
+    np.savez_compressed(os.path.join(OUT, "svd_" + name + ".npz"), **d)
+    print(f"svd_{name:24s} {h}x{w} raw_ber={np.mean(raw_bits.reshape(-1)[:wm.size] != wm.reshape(-1)):.4f} "
+          f"payload_ok={np.array_equal(d['degenerated'], payload)}")
+
+
 def main():
     P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    run_svd_case("syn_64x96", orc.synthetic_frame(64, 96, 2), P8, 0, store_yuv=True)
+    run_svd_case("syn_240x320", orc.synthetic_frame(240, 320, 1001), P8, 0)
+    run_svd_case("syn_30x44", orc.synthetic_frame(30, 44, 5), P8, 0, store_yuv=True)
+    run_svd_case("syn_36x52", orc.synthetic_frame(36, 52, 6), P8, 7, store_yuv=True)
+    run_svd_case("edge_black_64x64", np.zeros((64, 64, 3), np.uint8), P8, 0)
+    run_svd_case("edge_white_64x64", np.full((64, 64, 3), 255, np.uint8), P8, 0)
     P5 = np.array([1, 0, 0, 1, 1])
     run_case("syn_16x24_L8_k0_a20", orc.synthetic_frame(16, 24, 1), P8, 0, 20, store_yuv=True)
     run_case("syn_64x96_L8_k0_a20", orc.synthetic_frame(64, 96, 2), P8, 0, 20, store_yuv=True)
@@ -92,6 +120,8 @@ def main():
     nat = np.asarray(Image.open("/root/reference/tests/media/imgs/frame63.jpeg").convert("RGB"))
     for n, (y, x) in enumerate([(300, 600), (700, 1200)]):
         run_case(f"frame63_crop{n}_L8_k0_a20", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0, 20)
+    for n, (y, x) in enumerate([(300, 600), (700, 1200)]):
+        run_svd_case(f"frame63_crop{n}", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0)
     qr = np.asarray(Image.open("/root/reference/tests/media/wms/qr.jpeg").convert("L"))
     run_case("frame63_crop_qr_k0_a20", np.ascontiguousarray(nat[256:256 + 256, 512:512 + 384]), qr, 0, 20,
              image_payload=True)

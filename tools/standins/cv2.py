@@ -14,11 +14,11 @@ COLOR_YUV2BGR = 84
 
 
 def dct(src):
-    return _o.dct8x8(src)
+    return _o.dct4x4(src) if src.shape == (4, 4) else _o.dct8x8(src)
 
 
 def idct(src):
-    return _o.idct8x8(src)
+    return _o.idct4x4(src) if src.shape == (4, 4) else _o.idct8x8(src)
 
 
 def cvtColor(src, code):

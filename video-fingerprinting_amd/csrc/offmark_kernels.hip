@@ -146,6 +146,14 @@ __device__ __forceinline__ void store_px8(uint8_t *p, const Px8 &v) {
     }
 }
 
+// Make the compiler forget what it knows about these registers.  Used where a kernel deliberately
+// RECOMPUTES per-pixel values from the raw bytes in a second pass: without it, CSE keeps the first
+// pass's 128+ floats alive across the whole SVD and spills.
+__device__ __forceinline__ void forget(Px8 &v) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(v.w[k]));
+}
+
 __device__ __forceinline__ float px_byte(const Px8 &v, int k) {   // k is a compile-time constant after unrolling
     return (float)((v.w[k >> 2] >> (8 * (k & 3))) & 0xffu);       // -> v_cvt_f32_ubyteN
 }
@@ -556,6 +564,243 @@ __global__ __launch_bounds__(kThreads) void mark_yuv32f_kernel(float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// DwtDctSvd codec: embed/dwt_dct_svd_encoder.py:19-45, extract/dwt_dct_svd_decoder.py:12-37
+// ------------------------------------------------------------------------------------------
+// Per 8x8 pixel tile the reference takes the Haar LL band of channel 1 (a 4x4 block B), runs
+// cv2.dct, np.linalg.svd, replaces the top singular value by (s0 // scale + 0.25 + 0.5*bit)*scale,
+// multiplies back, cv2.idct, inverse Haar.  The 4x4 DCT is orthonormal, so dct(B) has B's singular
+// values and u*diag(s')*v maps back to B + (s0' - s0) * u0 * v0^T: a rank-1 update of B, and the
+// inverse Haar spreads each LL change over its 2x2 pixels with weight 1/2.  No DCT is computed here.
+// There is no frame-global dependency: embed is ONE pass (6 B/px), detect one pass (3 B/px).
+
+constexpr float kHaar = 0.70710678118654752f;   // pywt's haar taps in float32
+
+// Top singular value (and, if WANT_UPDATE, the rank-1 update direction) of a 4x4 matrix by one-sided
+// Jacobi (Hestenes): rotate column pairs until they are orthogonal; column norms are then the
+// singular values.  Five fixed sweeps reach float32 accuracy for 4x4.
+struct Svd4 { float s0; float w[4]; float z[4]; };     // w = s0*u0, z = B^T w = s0^2 * v0
+
+template <bool WANT_UPDATE>
+__device__ __forceinline__ Svd4 svd4_top(const float (&B)[4][4]) {
+    float A[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[i][j] = B[i][j];
+#pragma unroll 1
+    for (int sweep = 0; sweep < 5; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                float alpha = 0.f, beta = 0.f, gamma = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    alpha = fmaf(A[i][p], A[i][p], alpha);
+                    beta = fmaf(A[i][q], A[i][q], beta);
+                    gamma = fmaf(A[i][p], A[i][q], gamma);
+                }
+                // rotation angle that zeroes the pair's inner product; gamma == 0 -> identity (t = 0)
+                const float zeta = (beta - alpha) / (2.f * gamma);
+                float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(fmaf(zeta, zeta, 1.f)));
+                t = (gamma == 0.f || !(fabsf(zeta) < 3.0e38f)) ? 0.f : t;
+                const float c = 1.f / sqrtf(fmaf(t, t, 1.f));
+                const float sn = c * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float ap = A[i][p], aq = A[i][q];
+                    A[i][p] = fmaf(c, ap, -sn * aq);
+                    A[i][q] = fmaf(sn, ap, c * aq);
+                }
+            }
+    }
+    float n[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n[j] = fmaf(A[3][j], A[3][j], fmaf(A[2][j], A[2][j], fmaf(A[1][j], A[1][j], A[0][j] * A[0][j])));
+    int k = 0;
+    float best = n[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (n[j] > best) { best = n[j]; k = j; }
+    Svd4 r;
+    r.s0 = sqrtf(best);
+    if constexpr (WANT_UPDATE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.w[i] = k == 0 ? A[i][0] : k == 1 ? A[i][1] : k == 2 ? A[i][2] : A[i][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.z[j] = fmaf(B[3][j], r.w[3], fmaf(B[2][j], r.w[2], fmaf(B[1][j], r.w[1], B[0][j] * r.w[0])));
+    }
+    return r;
+}
+
+// np.float32 floor division by a positive scale (numpy: via fmod, exact for near-integers)
+__device__ __forceinline__ float floor_div_pos(float a, float b) {
+    const float m = fmodf(a, b);
+    return rintf((a - m) / b);
+}
+
+// One row of the Haar LL band from two pixel rows of U, in PyWavelets' order: axis -2 (the row
+// pair) first, then axis -1.  Building B row pair by row pair means U itself is never stored.
+__device__ __forceinline__ void haar_ll_row(const float (&top)[8], const float (&bot)[8], float (&brow)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float lo0 = top[2 * j] * kHaar + bot[2 * j] * kHaar;
+        const float lo1 = top[2 * j + 1] * kHaar + bot[2 * j + 1] * kHaar;
+        brow[j] = lo0 * kHaar + lo1 * kHaar;
+    }
+}
+
+// The quantisation step of dwt_dct_svd_encoder.py:44 as a change of B: dB[i][j] (already halved for
+// the inverse Haar, i.e. the amount to add to each of the 2x2 pixels' U).
+__device__ __forceinline__ void svd_update(const float (&B)[4][4], int bit, float scale, float (&dU)[4][4]) {
+    const Svd4 r = svd4_top<true>(B);
+    const float s_new = (floor_div_pos(r.s0, scale) + 0.25f + 0.5f * (float)bit) * scale;
+    if (r.s0 > 0.f) {
+        const float g = 0.5f * (s_new - r.s0) / (r.s0 * r.s0 * r.s0);      // (s0'-s0) * (w/s0) (z/s0^2)^T / 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dU[i][j] = g * r.w[i] * r.z[j];
+    } else {                                                                 // LAPACK on a zero block: u0 = v0 = e0
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dU[i][j] = (i == 0 && j == 0) ? 0.5f * s_new : 0.f;
+    }
+}
+
+__device__ __forceinline__ int svd_read_bit(const float (&B)[4][4], float scale) {
+    return fmodf(svd4_top<false>(B).s0, scale) > scale * 0.5f ? 1 : 0;       // dwt_dct_svd_decoder.py:36
+}
+
+struct SvdArgs {
+    const uint8_t *wm;        // [n_wm][N]           (embed)
+    const int32_t *wm_row;    // [frames] or null
+    int32_t *counts;          // [frames][L] or null (detect / verify)
+    uint8_t *bits;            // [frames][N] or null
+    int N, L;
+    float scale;
+};
+
+constexpr int SVD_DETECT = 0, SVD_EMBED = 1, SVD_EMBED_VERIFY = 2;
+
+template <bool ALIGNED, int MODE>
+__global__ __launch_bounds__(kThreads, 3) void svd_rgb8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                               Geom g, SvdArgs a) {
+    __shared__ int hist[kHistMax];
+    const int t = threadIdx.x;
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * kThreads + t;
+    const bool valid = c < g.nblk;
+    const bool want_counts = MODE != SVD_EMBED && a.counts != nullptr;
+    const bool use_hist = want_counts && a.L <= kHistMax;
+    if (use_hist) {
+        for (int k = t; k < a.L; k += kThreads) hist[k] = 0;
+        __syncthreads();
+    }
+    const int cc = valid ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<ALIGNED>(in + off + (size_t)r * pitch);
+    float B[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float y[8], u0[8], u1[8];
+        row_yu(raw[2 * i], y, u0);
+        row_yu(raw[2 * i + 1], y, u1);
+        haar_ll_row(u0, u1, B[i]);
+    }
+    int bit = 0;
+    if constexpr (MODE == SVD_DETECT) {
+        bit = svd_read_bit(B, a.scale);
+    } else {
+        float dU[4][4];
+        const int row = a.wm_row ? a.wm_row[f] : 0;
+        svd_update(B, a.wm[(size_t)row * a.N + cc], a.scale, dU);
+        float uprev[8];                                        // marked U of the even row of a pair (verify)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) forget(raw[r]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const Px8 &px = raw[r];
+            Px8 o = px;                                        // channel 2 is untouched (see mark_rgb8_kernel)
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float c0 = px_byte(px, 3 * x), c1 = px_byte(px, 3 * x + 1), c2 = px_byte(px, 3 * x + 2);
+                const float y = fmaf(c0, KY0, fmaf(c1, KY1, c2 * KY2));
+                const float u = fmaf(c0 - y, KU, KDELTA);
+                const float v = fmaf(c2 - y, KV, KDELTA);
+                const float u2 = u + dU[r >> 1][x >> 1];
+                const float ud = u2 - KDELTA, vd = v - KDELTA;
+                o.w[(3 * x) >> 2] = put_u8(fmaf(ud, KI_B, y), (3 * x) & 3, o.w[(3 * x) >> 2]);
+                o.w[(3 * x + 1) >> 2] = put_u8(fmaf(vd, KI_GV, fmaf(ud, KI_GU, y)), (3 * x + 1) & 3, o.w[(3 * x + 1) >> 2]);
+            }
+            if (valid) store_px8<ALIGNED>(out + off + (size_t)r * pitch, o);
+            if constexpr (MODE == SVD_EMBED_VERIFY) {          // what the detector will see: the rounded u8 pixels
+                float y[8], un[8];
+                row_yu(o, y, un);
+                if (r & 1) haar_ll_row(uprev, un, B[r >> 1]);
+                else {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) uprev[x] = un[x];
+                }
+            }
+        }
+        if constexpr (MODE == SVD_EMBED_VERIFY) bit = svd_read_bit(B, a.scale);
+    }
+    if constexpr (MODE != SVD_EMBED) {
+        if (valid) {
+            if (a.bits) a.bits[(size_t)f * a.N + c] = (uint8_t)bit;
+            if (want_counts && bit) {
+                const int pos = c % a.L;
+                if (use_hist) atomicAdd(&hist[pos], 1);
+                else atomicAdd(&a.counts[(size_t)f * a.L + pos], 1);
+            }
+        }
+        if (use_hist) {
+            __syncthreads();
+            for (int k = t; k < a.L; k += kThreads) {
+                const int v = hist[k];
+                if (v) atomicAdd(&a.counts[(size_t)f * a.L + k], v);
+            }
+        }
+    }
+}
+
+// Plugin-level float32 YUV frames: only channel 1 is read (and, for embed, written).
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 3) void svd_yuv32f_kernel(float *__restrict__ yuv, Geom g, SvdArgs a) {
+    const int f = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= g.nblk) return;
+    int bi, bj;
+    divmod_small(c, g.wb, g.inv_wb, bi, bj);
+    float *p = yuv + (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3 + 1;
+    const int pitch = g.W * 3;
+    float U[8][8], B[4][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) U[r][x] = p[(size_t)r * pitch + 3 * x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) haar_ll_row(U[2 * i], U[2 * i + 1], B[i]);
+    if constexpr (MODE == SVD_DETECT) {
+        a.bits[(size_t)f * a.N + c] = (uint8_t)svd_read_bit(B, a.scale);
+    } else {
+        float dU[4][4];
+        const int row = a.wm_row ? a.wm_row[f] : 0;
+        svd_update(B, a.wm[(size_t)row * a.N + c], a.scale, dU);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int x = 0; x < 8; ++x) p[(size_t)r * pitch + 3 * x] = U[r][x] + dU[r >> 1][x >> 1];
+    }
+}
+
 // DeShuffler.degenerate's epilogue on the device (de_shuffler.py:17-22) for a batch of frames:
 // mean of bits[i::L] from the counts, undo the key permutation, threshold strictly above the
 // mid-range of the L means.  One workgroup per frame; float64 like the reference.
@@ -625,11 +870,11 @@ int g_fuse_verify = 1;    // ofmk_embed_detect_rgb8: 1 = fused mark+analyze kern
 
 // Optional per-launch HIP-event timing (bench.py): events are created by ofmk_timing_enable(),
 // recorded on the launch stream around every kernel, and read back by ofmk_timing_collect().
-enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_COUNT = 4 };
+enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_SVD = 4, KIND_COUNT = 5 };
 struct TimingRec { hipEvent_t a, b; int kind; };
 TimingRec *g_trec = nullptr;
 int g_trec_cap = 0, g_trec_used = 0;
-unsigned g_trec_mask = 0xF;     // which kernel kinds get bracketed
+unsigned g_trec_mask = 0x1F;     // which kernel kinds get bracketed
 
 struct ScopedTiming {      // records the "after" event when it goes out of scope
     hipStream_t s;
@@ -836,6 +1081,37 @@ int detect_chunk(const void *in, int src, int f0, int cf, int H, int W, int L, d
     return finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, false, s);
 }
 
+// ---- DwtDctSvd codec ---------------------------------------------------------------------------
+int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mode, SvdArgs a, hipStream_t s) {
+    Workspace none;
+    none.plane = 0;
+    const Geom g = make_geom(H, W, none);
+    const bool al = aligned_rows(in, W, 1) && (mode == SVD_DETECT || aligned_rows(out, W, 1));
+    if (a.counts) HIP_TRY(hipMemsetAsync(a.counts, 0, (size_t)n * a.L * sizeof(int32_t), s));
+    if (a.bits && a.N > g.nblk) HIP_TRY(hipMemsetAsync(a.bits, 0, (size_t)n * a.N, s));   // entries past (H/8)(W/8) stay 0
+    for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
+        const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
+        const size_t fo = (size_t)f0 * g.frame_stride;
+        SvdArgs b = a;
+        if (b.wm_row) b.wm_row += f0;
+        if (b.counts) b.counts += (size_t)f0 * a.L;
+        if (b.bits) b.bits += (size_t)f0 * a.N;
+        const dim3 grid = block_grid(g, cf);
+        ScopedTiming timing(KIND_SVD, s);
+#define OFMK_SVD_LAUNCH(AL, MD) hipLaunchKernelGGL((svd_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
+        if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT); else OFMK_SVD_LAUNCH(false, SVD_DETECT); }
+        else if (mode == SVD_EMBED) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED); else OFMK_SVD_LAUNCH(false, SVD_EMBED); }
+        else { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED_VERIFY); else OFMK_SVD_LAUNCH(false, SVD_EMBED_VERIFY); }
+#undef OFMK_SVD_LAUNCH
+    }
+    HIP_TRY(hipGetLastError());
+    if (mode != SVD_DETECT && in != out && (H % 8 || W % 8)) {
+        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
+        HIP_TRY(hipGetLastError());
+    }
+    return OFMK_OK;
+}
+
 int check_embed_args(const void *in, const void *out, int n, int H, int W, const uint8_t *wm, int n_wm) {
     int rc = check_dims(n, H, W);
     if (rc) return rc;
@@ -992,6 +1268,76 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, c
     return launch_mark_rgb8(in, out, n, H, W, wm, nullptr, alpha, ws, fused != 0, static_cast<hipStream_t>(stream));
 }
 
+int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
+                        const int32_t *wm_row, double scale, void *stream) {
+    int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
+    if (rc) return rc;
+    if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
+    SvdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
+    return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED, a, static_cast<hipStream_t>(stream));
+}
+
+int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double scale, int32_t *counts, uint8_t *bits,
+                         void *stream) {
+    int rc = check_detect_args(in, n, H, W, L, counts, bits);
+    if (rc) return rc;
+    if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
+    SvdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.counts = counts; a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = L; a.scale = (float)scale;
+    return launch_svd_rgb8(in, nullptr, n, H, W, SVD_DETECT, a, static_cast<hipStream_t>(stream));
+}
+
+int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
+                               const int32_t *wm_row, double scale, int L, int32_t *counts, uint8_t *bits,
+                               void *stream) {
+    int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
+    if (rc) return rc;
+    if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
+    if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
+    SvdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.wm = wm; a.wm_row = wm_row; a.counts = counts; a.bits = bits;
+    a.N = (int)((long long)H * W / 64); a.L = L; a.scale = (float)scale;
+    return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, a, static_cast<hipStream_t>(stream));
+}
+
+int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
+                           double scale, void *stream) {
+    int rc = check_embed_args(yuv, yuv, n, H, W, wm, n_wm);
+    if (rc) return rc;
+    if (!(scale > 0) || n > kMaxChunk) return fail(OFMK_E_ARG, "bad scale or too many frames%s");
+    SvdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
+    Workspace none;
+    none.plane = 0;
+    const Geom g = make_geom(H, W, none);
+    hipLaunchKernelGGL((svd_yuv32f_kernel<SVD_EMBED>), block_grid(g, n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), yuv, g, a);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, double scale, uint8_t *bits, void *stream) {
+    int rc = check_dims(n, H, W);
+    if (rc) return rc;
+    if (!yuv || !bits) return fail(OFMK_E_ARG, "null pointer%s");
+    if (!(scale > 0) || n > kMaxChunk) return fail(OFMK_E_ARG, "bad scale or too many frames%s");
+    SvdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
+    Workspace none;
+    none.plane = 0;
+    const Geom g = make_geom(H, W, none);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.N > g.nblk) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
+    hipLaunchKernelGGL((svd_yuv32f_kernel<SVD_DETECT>), block_grid(g, n), dim3(kThreads), 0, s, const_cast<float *>(yuv), g, a);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
 int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm, uint8_t *payload,
                               void *stream) {
     if (!counts || !perm || !payload) return fail(OFMK_E_ARG, "null pointer%s");
@@ -1004,7 +1350,7 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
 
 int ofmk_timing_enable(int max_launches, unsigned kind_mask) {
     if (g_trec) return fail(OFMK_E_ARG, "timing already enabled%s");
-    g_trec_mask = kind_mask ? kind_mask : 0xF;
+    g_trec_mask = kind_mask ? kind_mask : 0x1F;
     if (max_launches < 1) return fail(OFMK_E_ARG, "max_launches must be positive%s");
     g_trec = new TimingRec[max_launches];
     for (int i = 0; i < max_launches; ++i) {

@@ -18,6 +18,8 @@ SYMBOLS = (
     "ofmk_embed_detect_rgb8", "ofmk_encode_yuv32f", "ofmk_decode_yuv32f", "ofmk_debug_planes",
     "ofmk_stage_analyze_rgb8", "ofmk_stage_mark_rgb8", "ofmk_hbm_copy", "ofmk_set_fused_verify",
     "ofmk_timing_enable", "ofmk_timing_collect", "ofmk_timing_disable", "ofmk_payloads_from_counts",
+    "ofmk_svd_embed_rgb8", "ofmk_svd_detect_rgb8", "ofmk_svd_embed_detect_rgb8", "ofmk_svd_encode_yuv32f",
+    "ofmk_svd_decode_yuv32f",
 )
 
 
@@ -64,6 +66,14 @@ def load():
     lib.ofmk_set_fused_verify.restype = None
     lib.ofmk_payloads_from_counts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.ofmk_payloads_from_counts.restype = i32
+    lib.ofmk_svd_embed_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f64, vp]
+    lib.ofmk_svd_detect_rgb8.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, vp]
+    lib.ofmk_svd_embed_detect_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f64, i32, vp, vp, vp]
+    lib.ofmk_svd_encode_yuv32f.argtypes = [vp, i32, i32, i32, vp, i32, vp, f64, vp]
+    lib.ofmk_svd_decode_yuv32f.argtypes = [vp, i32, i32, i32, f64, vp, vp]
+    for name in ("ofmk_svd_embed_rgb8", "ofmk_svd_detect_rgb8", "ofmk_svd_embed_detect_rgb8",
+                 "ofmk_svd_encode_yuv32f", "ofmk_svd_decode_yuv32f"):
+        getattr(lib, name).restype = i32
     lib.ofmk_timing_enable.argtypes = [i32, C.c_uint]
     lib.ofmk_timing_enable.restype = i32
     lib.ofmk_timing_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]

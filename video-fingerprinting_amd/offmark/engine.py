@@ -163,6 +163,57 @@ class DctEngine:
                                                _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
         return counts, bits
 
+    # -- DwtDctSvd codec (one pass, no workspace) ---------------------------------------------------
+    def svd_embed(self, frames, wm, scale=15, wm_row=None, out=None):
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        wm = self._wm(wm, H * W // 64)
+        rows = self._rows(wm_row, n)
+        if out is None:
+            out = t.empty_like(frames)
+        _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
+                                                _hip.ptr(rows), float(scale), _hip.current_stream()))
+        return out
+
+    def svd_detect(self, frames, L, scale=15, want_bits=False):
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
+        _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), float(scale), counts.data_ptr(),
+                                                 _hip.ptr(bits), _hip.current_stream()))
+        return counts, bits
+
+    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False):
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        wm = self._wm(wm, H * W // 64)
+        rows = self._rows(wm_row, n)
+        if out is None:
+            out = t.empty_like(frames)
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
+        _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
+                                                       wm.shape[0], _hip.ptr(rows), float(scale), int(L),
+                                                       counts.data_ptr(), _hip.ptr(bits), _hip.current_stream()))
+        return out, counts, bits
+
+    def svd_encode_yuv(self, yuv, wm, scale=15):
+        t = self.torch
+        n, H, W = self._check_frames(yuv, t.float32)
+        wm = self._wm(wm, H * W // 64)
+        _hip.check(self.lib.ofmk_svd_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], None,
+                                                   float(scale), _hip.current_stream()))
+        return yuv
+
+    def svd_decode_yuv(self, yuv, scale=15):
+        t = self.torch
+        n, H, W = self._check_frames(yuv, t.float32)
+        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device)
+        _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, float(scale), bits.data_ptr(),
+                                                   _hip.current_stream()))
+        return bits
+
     # -- parity planes ----------------------------------------------------------------------------
     def debug_planes(self, frame, alpha=20, wm=None):
         """One frame (u8 [H,W,3] or f32 YUV [H,W,3], CUDA).  Returns a dict of host numpy planes."""

@@ -1,0 +1,35 @@
+"""DwtDctSvdDecoder on the MI355X.  Mirrors offmark.extract.dwt_dct_svd_decoder.DwtDctSvdDecoder
+(reference src/offmark/extract/dwt_dct_svd_decoder.py:5-37): decode(yuv) -> float64 (1, H*W//64).
+This is the codec tests/detect.py constructs.  No CPU fallback."""
+import numpy as np
+
+from ..embed.dwt_dct_svd_encoder import _single_scale
+from ..engine import DctEngine
+
+
+class DwtDctSvdDecoder:
+    def __init__(self, key=None, scales=[0, 15, 0], blk=4):
+        self.key = key
+        self.scales = scales
+        self.blk = blk
+        self._scale = _single_scale(scales, blk)
+        self._engine = None
+
+    @property
+    def engine(self) -> DctEngine:
+        if self._engine is None:
+            self._engine = DctEngine()
+        return self._engine
+
+    def decode(self, yuv):
+        if yuv.dtype != np.float32 or yuv.ndim != 3 or yuv.shape[2] != 3:
+            raise ValueError("decode expects a float32 (H, W, 3) YUV array")
+        t = self.engine.torch
+        dev = t.from_numpy(np.ascontiguousarray(yuv)).to(self.engine.device).unsqueeze(0)
+        bits = self.engine.svd_decode_yuv(dev, scale=self._scale)
+        self.block_num = bits.shape[1]
+        return bits.cpu().numpy().astype(np.float64).reshape(1, -1)
+
+    def decode_frames_u8(self, frames, payload_len, want_bits=False):
+        """frames: CUDA uint8 [n, H, W, 3] -> (counts int32 [n, L] on device, bits or None)."""
+        return self.engine.svd_detect(frames, payload_len, scale=self._scale, want_bits=want_bits)
