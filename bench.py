@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = engine default)")
     ap.add_argument("--alpha", type=float, default=20.0)
+    ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
+                    help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (a one-GPU box cannot run RCCL across ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket kernels with HIP events (roofline becomes null)")
@@ -85,7 +90,9 @@ def main():
     from offmark.generator.shuffler import Shuffler
     from offmark.synthetic import synthetic_frames
 
-    rank, world = init_from_env("nccl")
+    if a.single_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world = init_from_env(a.backend)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -110,9 +117,15 @@ def main():
 
     def enqueue(k):
         """GPU half of step k: embed, detect the marked frames, per-frame payloads, all-gather."""
-        _, counts, _ = eng.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=out)
+        if a.codec == "dct":
+            _, counts, _ = eng.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=out)
+        else:
+            _, counts, _ = eng.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=out)
         mine = eng.payloads(counts, N, perm_dev)                         # [n, L] uint8, on device
-        everyone = gather_payloads(mine)                                 # RCCL all-gather (N > 1)
+        if a.backend == "gloo" and world > 1:                            # rehearsal: gloo gathers host tensors
+            everyone = gather_payloads(mine.cpu(), equal_shards=True)
+        else:
+            everyone = gather_payloads(mine, equal_shards=True)          # RCCL all-gather (N > 1)
         host[k & 1].copy_(everyone, non_blocking=True)
         ready[k & 1].record()
         return mine
@@ -141,12 +154,12 @@ def main():
         run(a.warmup)
     launches_per_step = 5 * ((n + chunk - 1) // chunk)      # upper bound (4 with the fused verify kernel)
     use_events = not a.no_kernel_events
-    KINDS = ("analyze", "finalize", "mark", "mark_fused")
-    DOMINANT = "mark_fused"
+    KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd")
+    DOMINANT = "mark_fused" if a.codec == "dct" else "svd"
 
     def collect():
-        ms = (ctypes.c_double * 4)()
-        cnt = (ctypes.c_int * 4)()
+        ms = (ctypes.c_double * 5)()
+        cnt = (ctypes.c_int * 5)()
         _hip.check(lib.ofmk_timing_collect(ms, cnt))
         lib.ofmk_timing_disable()
         return {k: dict(ms_total=ms[i], launches=cnt[i]) for i, k in enumerate(KINDS)}
@@ -159,7 +172,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,7 +180,7 @@ def main():
     if use_events:
         timed = collect()                      # dominant kernel, bracketed inside the timed region
         extra_steps = min(a.steps, 5)          # everything else: separate instrumented pass
-        _hip.check(lib.ofmk_timing_enable(launches_per_step * extra_steps + 16, 0xF))
+        _hip.check(lib.ofmk_timing_enable(launches_per_step * extra_steps + 16, 0x1F))
         run(extra_steps)
         torch.cuda.synchronize()
         kern = collect()
@@ -207,8 +220,9 @@ def main():
         # algorithmic bytes per frame and kernel: analyze reads the frame (3 B/px);
         # mark reads it again and writes the marked frame (6 B/px); the fused mark+verify kernel
         # moves the same 6 B/px and spares detect's 3 B/px read.  Sum over a step = 9 B/px.
-        alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes}
-        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>"}
+        alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes, "svd": 2 * frame_bytes}
+        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>",
+                 "svd": "svd_rgb8_kernel<embed+verify>"}
         per = {}
         for k, v in kern.items():
             if not v["launches"]:
@@ -240,7 +254,7 @@ def main():
                     frac_of_measured_copy=round(achieved / copy_gbps, 4))
 
     base = None
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.codec == "dct":
         base = cpu_baseline(frames[:128].cpu().numpy(), wm, a.alpha, a.cpu_seconds)
 
     path_gbps = fps * 9 * H * W / 1e9                                   # 9 B/px per embed+detect frame
@@ -249,8 +263,9 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic {W}x{H} u8 RGB x{n} frames per GPU, DCT embed+detect+vote "
-                               "(BASELINE.json configs[1])",
+        "config": {"workload": f"synthetic {W}x{H} u8 RGB x{n} frames per GPU, "
+                               f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} embed+detect+vote "
+                               f"(BASELINE.json configs[{2 if H >= 2160 else 1}])", "codec": a.codec,
                    "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
                    "chunk_frames": chunk, "sharding": f"frames, {world} rank(s), one RCCL all-gather of payloads"},
         "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,

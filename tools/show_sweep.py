@@ -4,6 +4,6 @@ for l in open(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/sweep.log'):
     if l.startswith('{'):
         d = json.loads(l); k = d['kernels']
         row = [f"{d['value']:.0f} fps", f"{d['ms_per_step']} ms/step", f"kern {d.get('kernel_ms_per_step')}"]
-        for name in ('analyze', 'mark', 'mark_fused', 'finalize'):
+        for name in ('analyze', 'mark', 'mark_fused', 'finalize', 'svd'):
             if name in k: row.append(f"{name} {k[name]['avg_launch_ms']} ms {k[name].get('achieved_GBps','')}")
         print('   ', ' | '.join(row), d['payload_bit_exact'])

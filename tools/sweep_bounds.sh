@@ -8,6 +8,6 @@ cp $LIB /tmp/lib_orig.so
 for cfg in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared $cfg $SRC -o $LIB
   echo "== $cfg" >> gpurun_out/sweep.log
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline >> gpurun_out/sweep.log 2>>gpurun_out/sweep.err
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS >> gpurun_out/sweep.log 2>>gpurun_out/sweep.err
 done
 cp /tmp/lib_orig.so $LIB

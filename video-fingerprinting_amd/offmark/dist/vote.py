@@ -53,13 +53,20 @@ def payloads_from_counts(counts, n_bits: int, perm):
     return (payload > thr).to(torch.uint8)
 
 
-def gather_payloads(local):
-    """all-gather per-frame payloads [n_local, L] uint8 -> [n_total, L] in rank order (ragged ok)."""
+def gather_payloads(local, equal_shards: bool = False):
+    """all-gather per-frame payloads [n_local, L] uint8 -> [n_total, L] in rank order.
+    ``equal_shards=True`` promises every rank holds the same number of frames: one collective, no size
+    exchange and no host synchronisation (the benchmark's steady state).  Otherwise ragged shards are
+    handled with a size exchange and padding."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
+    if equal_shards:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
     n_local = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)
