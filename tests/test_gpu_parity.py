@@ -431,3 +431,32 @@ def test_config5_leak_identification_with_build_defined_attacks(eng):
     for name, t in (("scale 2/3", scaled), ("crop 16", cropped)):
         got = identify(t.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1))
         print(f"attack {name}: recovered {sum(a == b for a, b in zip(got, chosen))}/{S} copies (not gated)")
+
+
+def test_c_abi_calls_are_graph_capturable(eng):
+    """include/offmark_hip.h promises no allocation and no synchronisation inside the compute calls:
+    a whole embed+detect+payload step must capture into a HIP graph and replay with identical results."""
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.synthetic import synthetic_frames
+    H, W, n = 240, 320, 16
+    N = H * W // 64
+    frames = synthetic_frames(n, H, W, seed=77)
+    wm = cuda(orc.shuffle_generate(P8, (1, N), 0).astype(np.uint8))
+    perm = torch.as_tensor(DeShuffler(key=0).set_shape((8,)).payload_idx, dtype=torch.int32).cuda()
+    out = torch.empty_like(frames)
+    ref_out, ref_counts, _ = eng.embed_detect(frames, wm, L=8)
+    ref_pay = eng.payloads(ref_counts, N, perm)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng.embed_detect(frames, wm, L=8, out=out)          # warm-up on the capture stream
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            _, counts, _ = eng.embed_detect(frames, wm, L=8, out=out)
+            pay = eng.payloads(counts, N, perm)
+    out.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(pay, ref_pay)

@@ -1,0 +1,65 @@
+"""Property tests (hypothesis) of the host-side codecs against the oracle: random payload lengths, keys,
+capacities and bit-error patterns.  CPU only."""
+import warnings
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import offmark_oracle as orc
+from offmark.degenerator.de_grayscale import DeGrayScale
+from offmark.degenerator.de_shuffler import DeShuffler
+from offmark.engine import payload_means
+from offmark.generator.grayscale import GrayScale
+from offmark.generator.shuffler import Shuffler
+
+keys = st.integers(min_value=0, max_value=2**31 - 1)
+
+
+@settings(max_examples=150, deadline=None)
+@given(L=st.integers(1, 40), cap=st.integers(1, 700), key=keys, seed=st.integers(0, 10**6))
+def test_shuffler_roundtrip_and_oracle_agreement(L, cap, key, seed):
+    rng = np.random.default_rng(seed)
+    payload = rng.integers(0, 2, size=L)
+    wm = Shuffler(key=key).generate_wm(payload, (1, cap))
+    assert wm.shape == (1, cap) and np.array_equal(wm, orc.shuffle_generate(payload, (1, cap), key))
+    noisy = wm.astype(np.float64).reshape(-1).copy()
+    flips = rng.random(cap) < 0.15
+    noisy[flips] = 1 - noisy[flips]
+    deg = DeShuffler(key=key).set_shape(payload.shape)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.deshuffle(noisy, L, key)
+        got = deg.degenerate(noisy)
+    assert np.array_equal(got, ref)
+    counts = np.array([noisy[i::L].sum() for i in range(L)]).astype(np.int64)
+    assert np.array_equal(deg.degenerate_counts(counts, cap), ref)
+    if cap >= 40 * L and 0 < payload.sum() < L and not flips.any():
+        assert np.array_equal(got, payload)            # clean, non-constant payload survives the round trip
+
+
+@settings(max_examples=60, deadline=None)
+@given(h=st.integers(1, 9), w=st.integers(1, 9), cap=st.integers(1, 500), key=keys, seed=st.integers(0, 10**6))
+def test_grayscale_codecs_match_oracle(h, w, cap, key, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wm = GrayScale(key=key).generate_wm(img, (1, cap))
+        assert np.array_equal(wm, orc.grayscale_generate(img, (1, cap), key))
+        bits = wm.astype(np.float64)
+        got = DeGrayScale(key=key).set_shape(img.shape).degenerate(bits)
+        assert got.shape == img.shape and np.array_equal(got, orc.degrayscale(bits, img.shape, key))
+
+
+@settings(max_examples=100, deadline=None)
+@given(L=st.integers(1, 64), N=st.integers(0, 2000))
+def test_payload_means_slice_lengths(L, N):
+    bits = np.ones(N)
+    counts = np.array([bits[i::L].sum() for i in range(L)])
+    with np.errstate(all="ignore"):
+        means = payload_means(counts, N, L)
+    for i in range(L):
+        if len(bits[i::L]):
+            assert means[i] == 1.0
+        else:
+            assert np.isnan(means[i])
