@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = engine default)")
     ap.add_argument("--alpha", type=float, default=20.0)
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2 = alternate steps between two HIP streams (own workspace and output buffer each)")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
                     help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
@@ -109,6 +111,9 @@ def main():
     deg = DeShuffler(key=0).set_shape(PAYLOAD.shape)
     chunk = a.chunk or default_chunk_frames(H, W)
     eng = DctEngine(device=dev, chunk_frames=chunk)
+    lanes = [dict(eng=eng, out=out, stream=torch.cuda.current_stream())]
+    if a.streams == 2:
+        lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk), out=torch.empty_like(frames), stream=torch.cuda.Stream()))
     seg_ids = np.repeat(np.arange(world), n)             # one segment per rank
 
     perm_dev = torch.as_tensor(deg.payload_idx, dtype=torch.int32).to(dev)
@@ -117,17 +122,20 @@ def main():
 
     def enqueue(k):
         """GPU half of step k: embed, detect the marked frames, per-frame payloads, all-gather."""
-        if a.codec == "dct":
-            _, counts, _ = eng.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=out)
-        else:
-            _, counts, _ = eng.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=out)
-        mine = eng.payloads(counts, N, perm_dev)                         # [n, L] uint8, on device
-        if a.backend == "gloo" and world > 1:                            # rehearsal: gloo gathers host tensors
-            everyone = gather_payloads(mine.cpu(), equal_shards=True)
-        else:
-            everyone = gather_payloads(mine, equal_shards=True)          # RCCL all-gather (N > 1)
-        host[k & 1].copy_(everyone, non_blocking=True)
-        ready[k & 1].record()
+        lane = lanes[k % len(lanes)]
+        e = lane["eng"]
+        with torch.cuda.stream(lane["stream"]):
+            if a.codec == "dct":
+                _, counts, _ = e.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=lane["out"])
+            else:
+                _, counts, _ = e.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=lane["out"])
+            mine = e.payloads(counts, N, perm_dev)                       # [n, L] uint8, on device
+            if a.backend == "gloo" and world > 1:                        # rehearsal: gloo gathers host tensors
+                everyone = gather_payloads(mine.cpu(), equal_shards=True)
+            else:
+                everyone = gather_payloads(mine, equal_shards=True)      # RCCL all-gather (N > 1)
+            host[k & 1].copy_(everyone, non_blocking=True)
+            ready[k & 1].record()
         return mine
 
     def finish(k):

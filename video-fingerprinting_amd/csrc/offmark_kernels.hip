@@ -117,12 +117,25 @@ __device__ __forceinline__ int wave_sum(int v) {
 // ------------------------------------------------------------------------------------------
 struct Px8 { uint32_t w[6]; };   // 8 interleaved u8 RGB pixels = 24 bytes
 
+#ifndef OFMK_NT_LOAD
+#define OFMK_NT_LOAD 0
+#endif
+#ifndef OFMK_NT_STORE
+#define OFMK_NT_STORE 0
+#endif
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 template <bool ALIGNED>
 __device__ __forceinline__ Px8 load_px8(const uint8_t *p) {
     Px8 v;
     if constexpr (ALIGNED) {
+#if OFMK_NT_LOAD
+        const u32x2 *q = reinterpret_cast<const u32x2 *>(p);
+        const u32x2 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1), c = __builtin_nontemporal_load(q + 2);
+#else
         const uint2 *q = reinterpret_cast<const uint2 *>(p);
         const uint2 a = q[0], b = q[1], c = q[2];
+#endif
         v.w[0] = a.x; v.w[1] = a.y; v.w[2] = b.x; v.w[3] = b.y; v.w[4] = c.x; v.w[5] = c.y;
     } else {
 #pragma unroll
@@ -136,10 +149,16 @@ __device__ __forceinline__ Px8 load_px8(const uint8_t *p) {
 template <bool ALIGNED>
 __device__ __forceinline__ void store_px8(uint8_t *p, const Px8 &v) {
     if constexpr (ALIGNED) {
+#if OFMK_NT_STORE
+        u32x2 *q = reinterpret_cast<u32x2 *>(p);
+        u32x2 a = {v.w[0], v.w[1]}, b = {v.w[2], v.w[3]}, c = {v.w[4], v.w[5]};
+        __builtin_nontemporal_store(a, q); __builtin_nontemporal_store(b, q + 1); __builtin_nontemporal_store(c, q + 2);
+#else
         uint2 *q = reinterpret_cast<uint2 *>(p);
         q[0] = make_uint2(v.w[0], v.w[1]);
         q[1] = make_uint2(v.w[2], v.w[3]);
         q[2] = make_uint2(v.w[4], v.w[5]);
+#endif
     } else {
 #pragma unroll
         for (int k = 0; k < 24; ++k) p[k] = (uint8_t)(v.w[k >> 2] >> (8 * (k & 3)));
