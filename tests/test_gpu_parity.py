@@ -460,3 +460,41 @@ def test_c_abi_calls_are_graph_capturable(eng):
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(pay, ref_pay)
+
+
+@pytest.mark.parametrize("codec", ["dct", "dwtdctsvd"])
+def test_mark_copies_sidecars_and_leak_identification(eng, codec, tmp_path):
+    """mark_video_to_hls.py's flow (N copies per segment, verify, JSON sidecars) followed by
+    detect_watermarks.py's mapping branch on a leak assembled from the copies."""
+    import json
+    import torch
+    from offmark import fingerprint as fp
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.dist.vote import vote_segments
+    from offmark.synthetic import synthetic_frames
+    if codec == "dct":
+        from offmark.embed.dct_encoder import DctEncoder as Enc
+        from offmark.extract.dct_decoder import DctDecoder as Dec
+    else:
+        from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder as Enc
+        from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder as Dec
+    H, W, S, C, F = 240, 320, 6, 3, 10
+    frames = synthetic_frames(S * F, H, W, seed=6000)
+    # segments 1..S: the reference's payload for (segment 0, copy 0) is all zeros, which its own mid-range
+    # threshold cannot decode reliably (any raw bit error outvotes a constant payload, de_shuffler.py:20-21)
+    seg = np.repeat(np.arange(1, S + 1), F)
+    enc, dec = Enc(), Dec()
+    copies, side = fp.mark_segment_copies(enc, dec, frames, seg, C)
+    assert len(copies) == C and not side["failed_segments"]
+    assert side["segment_copies"]["total_marked_segments"] == S * C
+    assert side["segment_payloads"]["4_2"] == fp.payload_for_segment(4, 2).tolist()
+    paths = fp.write_sidecars(str(tmp_path), side)
+    assert [os.path.basename(p) for p in paths] == ["segment_payloads.json", "segment_copies.json"]
+    payloads = json.load(open(paths[0]))
+    chosen = fp.select_copies("120210", S, C)
+    leak = torch.cat([copies[chosen[s]][s * F:(s + 1) * F] for s in range(S)])
+    counts, _ = dec.decode_frames_u8(leak.contiguous(), 8)
+    votes = vote_segments(DeShuffler(key=0).set_shape((8,)).degenerate_counts(counts.cpu().numpy(), H * W // 64), seg)
+    rows = fp.identify_copies_with_payloads(votes, payloads, C)
+    assert [r["detected_copy_index"] for r in rows] == chosen and all(r["success"] for r in rows)
+    assert fp.identify_copies(votes) == chosen

@@ -63,3 +63,93 @@ def identify_copies(segment_votes: dict, segment_numbers=None) -> list[int | Non
         seg, copy = decode_pattern(pattern)
         out.append(copy if seg is not None and seg == s % 16 else None)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Marking N copies per segment, verifying them, and the reference's JSON sidecars
+# (tests/mark_video_to_hls.py:330-434).  The pixel work is one batched GPU call per copy.
+# ---------------------------------------------------------------------------------------------
+
+def mark_segment_copies(encoder, decoder, frames, segment_of_frame, num_copies: int, key=0, min_frequency: float = 0.5):
+    """Mark ``num_copies`` versions of every segment and verify each one.
+
+    encoder / decoder: HIP codecs offering ``encode_frames_u8`` / ``decode_frames_u8`` (DctEncoder+DctDecoder or
+    DwtDctSvdEncoder+DwtDctSvdDecoder).  frames: CUDA uint8 [n, H, W, 3]; segment_of_frame: int array [n].
+    Returns (copies, sidecars): copies[c] is the marked tensor of copy c; sidecars holds the dicts the
+    reference writes as segment_payloads.json / segment_copies.json / failed_segments.json, with the same
+    keys.  A copy fails verification when its per-segment vote differs from its payload or the winning
+    pattern covers fewer than ``min_frequency`` of the frames (mark_video_to_hls.py:381)."""
+    import torch
+    from .degenerator.de_shuffler import DeShuffler
+    from .dist.vote import vote_segments
+    from .generator.shuffler import Shuffler
+
+    seg = np.asarray(segment_of_frame)
+    segments = [int(s) for s in np.unique(seg)]
+    n, H, W, _ = frames.shape
+    N = H * W // 64
+    gen = Shuffler(key=key)
+    deg = DeShuffler(key=key).set_shape((8,))
+    index = {(s, c): i for i, (s, c) in enumerate((s, c) for s in segments for c in range(num_copies))}
+    table = np.stack([gen.generate_wm(payload_for_segment(s, c), (N,)) for s in segments for c in range(num_copies)])
+    table_dev = torch.from_numpy(table.astype(np.uint8)).to(frames.device)
+    copies, segment_payloads, failed = [], {}, []
+    segment_copies = {str(s): [] for s in segments}
+    for c in range(num_copies):
+        rows = np.array([index[(int(s), c)] for s in seg], dtype=np.int32)
+        marked = encoder.encode_frames_u8(frames, wm_rows=torch.from_numpy(rows).to(frames.device), wm_table=table_dev)
+        counts, _ = decoder.decode_frames_u8(marked, 8)
+        votes = vote_segments(deg.degenerate_counts(counts.cpu().numpy(), N), seg)
+        copies.append(marked)
+        for s in segments:
+            payload = payload_for_segment(s, c).tolist()
+            name = f"marked_seg{s}_copy{c}.mp4"
+            segment_payloads[f"{s}_{c}"] = payload
+            segment_copies[str(s)].append({"file": name, "payload": payload, "copy_index": c})
+            pattern, freq = votes[s]
+            if pattern is None or pattern.tolist() != payload or freq < min_frequency:
+                failed.append({"segment": name, "segment_number": s, "copy_index": c, "expected_pattern": payload,
+                               "detected_pattern": None if pattern is None else pattern.tolist(), "frequency": freq})
+    sidecars = {
+        "segment_payloads": segment_payloads,
+        "segment_copies": {"total_segments": len(segments), "copies_per_segment": num_copies,
+                           "total_marked_segments": len(segments) * num_copies, "segments": segment_copies},
+        "failed_segments": failed,
+    }
+    return copies, sidecars
+
+
+def write_sidecars(directory: str, sidecars: dict) -> list[str]:
+    """Write segment_payloads.json, segment_copies.json and (if any) failed_segments.json; returns the paths."""
+    import json
+    import os
+    os.makedirs(directory, exist_ok=True)
+    paths = []
+    for name in ("segment_payloads", "segment_copies", "failed_segments"):
+        if name == "failed_segments" and not sidecars[name]:
+            continue
+        path = os.path.join(directory, name + ".json")
+        with open(path, "w") as f:
+            json.dump(sidecars[name], f, indent=2)
+        paths.append(path)
+    return paths
+
+
+def identify_copies_with_payloads(segment_votes: dict, segment_payloads: dict, max_copies: int) -> list[dict]:
+    """The mapping branch of detect_watermarks.py:329-344, with the segment decoded once instead of once
+    per candidate copy: a copy matches when the segment's winning pattern equals that copy's recorded
+    payload; among matches the highest frequency wins.  Returns one dict per segment with the keys of the
+    reference's detection_results.json rows."""
+    rows = []
+    for s in sorted(segment_votes):
+        pattern, freq = segment_votes[s]
+        detected, best = None, 0
+        for c in range(max_copies):
+            expected = segment_payloads.get(f"{s}_{c}")
+            if expected is None or pattern is None:
+                continue
+            if list(np.asarray(pattern).tolist()) == list(expected) and freq > best:
+                best, detected = freq, c
+        rows.append({"segment_number": int(s), "detected_copy_index": detected, "match_frequency": best,
+                     "success": detected is not None})
+    return rows
