@@ -498,3 +498,68 @@ def test_mark_copies_sidecars_and_leak_identification(eng, codec, tmp_path):
     rows = fp.identify_copies_with_payloads(votes, payloads, C)
     assert [r["detected_copy_index"] for r in rows] == chosen and all(r["success"] for r in rows)
     assert fp.identify_copies(votes) == chosen
+
+
+def test_long_and_oversized_payloads_and_empty_inputs(eng):
+    """Payload longer than the LDS histogram (global-atomic path), payload longer than the frame's capacity
+    (trailing positions have empty slices -> numpy's nan semantics), and empty/invalid inputs."""
+    import torch
+    from offmark import _hip
+    from offmark.degenerator.de_shuffler import DeShuffler
+    lib = _hip.load()
+    H, W = 240, 320
+    N = H * W // 64
+    frame = orc.synthetic_frame(H, W, 1001)
+    for L in (3000, 1200, 2048, 2049):
+        rng = np.random.default_rng(L)
+        payload = rng.integers(0, 2, size=L)
+        wm = orc.shuffle_generate(payload, (1, N), 3)
+        marked, counts, bits = eng.embed_detect(cuda(frame[None]), wm, L=L, want_bits=True)
+        b = bits[0].cpu().numpy()
+        assert np.array_equal(counts[0].cpu().numpy(), np.array([b[i::L].sum() for i in range(L)]))
+        deg = DeShuffler(key=3).set_shape((L,))
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = orc.deshuffle(b.astype(np.float64), L, 3)
+        assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), N), ref)
+        perm = torch.as_tensor(deg.payload_idx, dtype=torch.int32).cuda()
+        assert np.array_equal(eng.payloads(counts, N, perm)[0].cpu().numpy(), ref)
+        if L <= N:
+            assert (ref == payload).mean() > 0.95          # one repeat per bit at most: nearly all survive
+    f = cuda(frame[None])
+    ws = eng.workspace(H, W, 1)
+    wm = cuda(orc.shuffle_generate(P8, (1, N), 0).astype(np.uint8))
+    s = _hip.current_stream()
+    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 0, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s) == -1
+    assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 0.0, s) == -1
+    assert lib.ofmk_svd_detect_rgb8(f.data_ptr(), 1, H, W, 8, 15.0, None, None, s) == -1
+    assert lib.ofmk_payloads_from_counts(None, 1, 8, N, None, None, s) == -1
+    unaligned = torch.empty(ws.numel() + 1, dtype=torch.uint8, device="cuda")[1:]
+    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 20.0, 0, unaligned.data_ptr(), ws.numel(), s) == -1
+    assert b"256-byte aligned" in lib.ofmk_last_error()
+
+
+def test_inplace_and_unaligned_frame_pointers(eng):
+    """In-place marking for both codecs, and frame pointers that are not 8-byte aligned (generic byte path)."""
+    import torch
+    frames = np.stack([orc.synthetic_frame(64, 96, 50 + i) for i in range(3)])
+    wm = orc.shuffle_generate(P8, (1, 96), 0)
+    ref = eng.embed(cuda(frames), wm)
+    buf = torch.empty(frames.size + 3, dtype=torch.uint8, device="cuda")
+    view = buf[3:].view(3, 64, 96, 3)                       # data_ptr % 8 == 3
+    view.copy_(cuda(frames))
+    assert view.data_ptr() % 8 != 0
+    out = torch.empty(frames.size + 5, dtype=torch.uint8, device="cuda")[5:].view(3, 64, 96, 3)
+    eng.embed(view, wm, out=out)
+    assert torch.equal(out, ref)
+    eng.embed(view, wm, out=view)                           # in place, unaligned
+    assert torch.equal(view, ref)
+    sref = eng.svd_embed(cuda(frames), wm)
+    inpl = cuda(frames)
+    eng.svd_embed(inpl, wm, out=inpl)
+    assert torch.equal(inpl, sref)
+    c1, b1 = eng.detect(ref, 8, want_bits=True)
+    c2, b2 = eng.detect(view, 8, want_bits=True)
+    assert torch.equal(c1, c2) and torch.equal(b1, b2)
