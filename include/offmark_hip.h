@@ -148,7 +148,8 @@ int ofmk_timing_collect(double *ms_by_kind /*[5]*/, int *launches_by_kind /*[5]*
 void ofmk_timing_disable(void);
 
 /* Process-wide switch for ofmk_embed_detect_rgb8: 1 (default) marks and analyzes the marked block
- * in one kernel; 0 runs the separate mark and analyze kernels (same results bit for bit). */
+ * in one kernel; 0 runs the separate mark and analyze kernels (same results bit for bit).  (2 selects an
+ * experimental single-pass variant for ofmk_stage_mark_rgb8, see tools/upper_bound.py.) */
 void ofmk_set_fused_verify(int on);
 
 #ifdef __cplusplus
