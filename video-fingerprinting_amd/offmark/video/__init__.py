@@ -1,0 +1,1 @@
+"""offmark-compatible package of the MI355X frame-watermark engine."""
