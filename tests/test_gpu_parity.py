@@ -431,6 +431,19 @@ def test_config5_leak_identification_with_build_defined_attacks(eng):
     for name, t in (("scale 2/3", scaled), ("crop 16", cropped)):
         got = identify(t.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1))
         print(f"attack {name}: recovered {sum(a == b for a, b in zip(got, chosen))}/{S} copies (not gated)")
+    # 4:2:0 chroma subsampling round trip (what FileEncoder's yuv420p output does to every marked frame,
+    # frame_writer.py:34): average U,V over 2x2, replicate back.  The reference's own robustness bar is
+    # ">= 75 % of segments keep their payload" through an HLS re-encode (segment_mark_detect_hls.py:500).
+    k = torch.tensor([[0.114, 0.587, 0.299], [-0.114 * 0.492 + 0.492, -0.587 * 0.492, -0.299 * 0.492],
+                      [-0.114 * 0.877, -0.587 * 0.877, -0.299 * 0.877 + 0.877]], device="cuda")
+    yuv = torch.einsum("kc,nchw->nkhw", k, x)
+    uv = torch.nn.functional.avg_pool2d(yuv[:, 1:], 2).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    y_, u_, v_ = yuv[:, 0], uv[:, 0], uv[:, 1]
+    back = torch.stack([y_ + 2.032 * u_, y_ - 0.395 * u_ - 0.581 * v_, y_ + 1.140 * v_], dim=1)
+    got = identify(back.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1))
+    kept = sum(a == b for a, b in zip(got, chosen))
+    print(f"attack 4:2:0 chroma round trip: recovered {kept}/{S} copies")
+    assert kept >= 0.75 * S
 
 
 def test_c_abi_calls_are_graph_capturable(eng):
