@@ -37,6 +37,10 @@ class ArrayFrameWriter(FrameWriter):
     def write(self, frame):
         self.frames.append(np.asarray(frame).astype(np.uint8))
 
+    def write_batch(self, frames):
+        kept = np.array(frames, dtype=np.uint8)          # one copy: the caller may reuse its buffer
+        self.frames.extend(kept)
+
     def close(self):
         self.closed = True
 
