@@ -1,0 +1,49 @@
+"""The C restatement (oracle/offmark_oracle.c) must agree BIT FOR BIT with the NumPy oracle and with the
+vectors captured from the reference's own modules.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import c_oracle
+import offmark_oracle as orc
+from conftest import GOLDEN, golden_cases
+
+P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_c_oracle_reproduces_reference_vectors(case):
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    alpha = float(g["alpha"])
+    marked, _ = c_oracle.mark_frames(g["frame"][None], g["wm"], alpha=alpha, legacy=False)    # goldens: numpy 2 semantics
+    assert np.array_equal(marked[0], g["marked"])
+    bits, _ = c_oracle.check_frames(g["marked"][None], alpha=alpha, legacy=False)
+    assert np.array_equal(bits[0], g["raw_bits"].reshape(-1))
+
+
+@pytest.mark.parametrize("legacy", [True, False])
+@pytest.mark.parametrize("shape,seed", [((240, 320), 1001), ((1080, 1920), 2000), ((30, 44), 5), ((2160, 3840), 3001)])
+def test_c_oracle_equals_numpy_oracle(shape, seed, legacy):
+    if shape[0] > 1080 and not legacy:
+        pytest.skip("one 4K comparison is enough")
+    H, W = shape
+    frame = orc.synthetic_frame(H, W, seed)
+    wm = orc.shuffle_generate(P8, (1, H * W // 64), 0)
+    promo = "legacy" if legacy else "nep50"
+    enc = orc.DctEncoderOracle(alpha=20, promotion=promo)
+    enc.read_wm(wm)
+    ref = orc.mark_frame(frame, enc)
+    got, _ = c_oracle.mark_frames(frame[None], wm, alpha=20, legacy=legacy)
+    assert np.array_equal(got[0], ref)
+    ref_bits = orc.check_frame(ref, orc.DctDecoderOracle(alpha=20, promotion=promo))
+    bits, _ = c_oracle.check_frames(ref[None], alpha=20, legacy=legacy)
+    assert np.array_equal(bits[0], ref_bits.reshape(-1))
+
+
+def test_c_oracle_threads_give_identical_results():
+    frames = np.stack([orc.synthetic_frame(240, 320, 1001 + i) for i in range(6)])
+    wm = orc.shuffle_generate(P8, (1, 1200), 0)
+    a, _ = c_oracle.mark_frames(frames, wm, threads=1)
+    b, used = c_oracle.mark_frames(frames, wm, threads=4)
+    assert used == 4 and np.array_equal(a, b)
