@@ -144,6 +144,33 @@ def test_pipeline_plumbing_with_in_memory_reader_writer():
     assert np.array_equal(best, P8) and freq == 1.0
 
 
+def test_extractor_accepts_duck_typed_reader_without_read_batch():
+    """The reference's plugin API is duck typing (frame_reader.py:13 "TODO extend ABC"): a reader with only
+    read()/close() must work with the per-frame path."""
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.video.extractor import Extractor
+
+    class Bare:
+        def __init__(self, frames):
+            self.frames, self.i, self.closed = frames, 0, False
+
+        def read(self):
+            self.i += 1
+            return self.frames[self.i - 1] if self.i <= len(self.frames) else None
+
+        def close(self):
+            self.closed = True
+
+    frame = orc.synthetic_frame(64, 96, 2)
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(orc.shuffle_generate(P8, (1, 96), 0))
+    marked = orc.mark_frame(frame, enc)
+    r = Bare([marked, marked])
+    ex = Extractor(r, orc.DctDecoderOracle(alpha=20), DeShuffler(key=0).set_shape(P8.shape))
+    ex.start()
+    assert r.closed and len(ex.patterns) == 2 and np.array_equal(ex.patterns[0], P8)
+
+
 def test_file_decoder_is_gated_on_ffmpeg():
     import shutil
     from offmark.video.frame_reader import FileDecoder

@@ -19,8 +19,8 @@ from . import _hip
 _CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 2 << 30))
 
 
-def default_chunk_frames(H: int, W: int) -> int:
-    return max(1, _CACHE_BUDGET_BYTES // (H * W * 3))
+def default_chunk_frames(H: int, W: int, bytes_per_sample: int = 1) -> int:
+    return max(1, _CACHE_BUDGET_BYTES // (H * W * 3 * bytes_per_sample))
 
 
 class DctEngine:
@@ -46,8 +46,8 @@ class DctEngine:
             self._ws = {key: ws}          # keep one; sizes rarely change within a job
         return ws
 
-    def _chunk(self, n, H, W):
-        c = self.chunk_frames or default_chunk_frames(H, W)
+    def _chunk(self, n, H, W, bytes_per_sample=1):
+        c = self.chunk_frames or default_chunk_frames(H, W, bytes_per_sample)
         return max(1, min(n, c))
 
     def _check_frames(self, frames, dtype):
@@ -145,7 +145,7 @@ class DctEngine:
         n, H, W = self._check_frames(yuv, t.float32)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n)
-        cf = self._chunk(n, H, W * 4)
+        cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], _hip.ptr(rows),
                                                float(alpha), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
@@ -157,7 +157,7 @@ class DctEngine:
         N = H * W // 64
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
-        cf = self._chunk(n, H, W * 4)
+        cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_decode_yuv32f(yuv.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
                                                _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))

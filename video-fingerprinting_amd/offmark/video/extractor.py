@@ -52,7 +52,7 @@ class Extractor:
         import torch
         L = self.degenerator.payload_len
         while True:
-            batch = self.frame_reader.read_batch(self.batch_frames) if hasattr(self.frame_reader, "read_batch") else None
+            batch = self.__next_batch()
             if batch is None:
                 logger.info("End of input stream")
                 break
@@ -63,6 +63,17 @@ class Extractor:
             for out in outs:
                 self.patterns.append(out)
                 logger.info(out)
+
+    def __next_batch(self):
+        if hasattr(self.frame_reader, "read_batch"):
+            return self.frame_reader.read_batch(self.batch_frames)
+        frames = []                                   # duck-typed reader with only read()/close()
+        while len(frames) < self.batch_frames:
+            f = self.frame_reader.read()
+            if f is None:
+                break
+            frames.append(f)
+        return np.stack(frames) if frames else None
 
     def __check_frame(self, frame_rgb):
         wm_frame_yuv = bgr2yuv(frame_rgb.astype(np.float32))
