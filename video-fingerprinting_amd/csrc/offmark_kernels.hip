@@ -560,25 +560,30 @@ __global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_r
         const Px8 &px = raw[r];
         const float dr = d * c2_of(r);
         Px8 o = px;       // channel 2 bytes stay: Y + 1.140*(V-0.5) = c2 - 2.2e-4*(c2 - Y), |error| < 0.05
+        float yv[8], uv[8];   // FUSED: Y and U of the MARKED row, i.e. of the rounded, clipped u8 pixels detect will see
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
             const float c0 = px_byte(px, 3 * x), c1 = px_byte(px, 3 * x + 1), c2 = px_byte(px, 3 * x + 2);
-            const float y = fmaf(c0, KY0, fmaf(c1, KY1, c2 * KY2));
+            const float t2 = c2 * KY2;
+            const float y = fmaf(c0, KY0, fmaf(c1, KY1, t2));
             const float u = fmaf(c0 - y, KU, KDELTA);          // cvtColor BGR2YUV
             const float v = fmaf(c2 - y, KV, KDELTA);
             const float u2 = fmaf(dr, c1_of(x), u);            // idct(dct(U) + d*e21) = U + d*c2[r]*c1[x]
             const float ud = u2 - KDELTA, vd = v - KDELTA;     // cvtColor YUV2BGR
             o.w[(3 * x) >> 2] = put_u8(fmaf(ud, KI_B, y), (3 * x) & 3, o.w[(3 * x) >> 2]);
             o.w[(3 * x + 1) >> 2] = put_u8(fmaf(vd, KI_GV, fmaf(ud, KI_GU, y)), (3 * x + 1) & 3, o.w[(3 * x + 1) >> 2]);
+            if constexpr (FUSED) {                             // channel 2 and its product are shared with the pass above
+                const float n0 = px_byte(o, 3 * x), n1 = px_byte(o, 3 * x + 1);
+                yv[x] = fmaf(n0, KY0, fmaf(n1, KY1, t2));
+                uv[x] = fmaf(n0 - yv[x], KU, KDELTA);
+            }
         }
         if (valid) store_px8<ALIGNED>(out + off + (size_t)r * pitch, o);
         if constexpr (FUSED) {
-            float y[8], u[8];
-            row_yu(o, y, u);           // what detect will see: the rounded, clipped u8 pixels
-            fold_u1(u1, r, proj1(u));
-            dct8(y);
+            fold_u1(u1, r, proj1(uv));
+            dct8(yv);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) R[r][k] = y[k];
+            for (int k = 0; k < 8; ++k) R[r][k] = yv[k];
         }
     }
     if constexpr (FUSED) {
