@@ -150,8 +150,12 @@ def main():
     host = [torch.empty((world * n, PAYLOAD.size), dtype=torch.uint8).pin_memory() for _ in range(2)]
     ready = [torch.cuda.Event() for _ in range(2)]
 
+    side = torch.cuda.Stream()                    # all-gather + download: off the compute stream, so a slow
+    handoff = [torch.cuda.Event() for _ in range(2)]   # peer never stalls this rank's next step
+
     def enqueue(k):
-        """GPU half of step k: embed, detect the marked frames, per-frame payloads, all-gather."""
+        """GPU half of step k: embed, detect the marked frames, per-frame payloads; then, on a side stream,
+        the all-gather of the payloads and their download into pinned memory."""
         lane = lanes[k % len(lanes)]
         e = lane["eng"]
         with torch.cuda.stream(lane["stream"]):
@@ -160,6 +164,10 @@ def main():
             else:
                 _, counts, _ = e.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=lane["out"])
             mine = e.payloads(counts, N, perm_dev)                       # [n, L] uint8, on device
+            handoff[k & 1].record()
+        with torch.cuda.stream(side):
+            side.wait_event(handoff[k & 1])
+            mine.record_stream(side)
             if a.backend == "gloo" and world > 1:                        # rehearsal: gloo gathers host tensors
                 everyone = gather_payloads(mine.cpu(), equal_shards=True)
             else:
