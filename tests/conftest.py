@@ -1,6 +1,7 @@
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +45,13 @@ def _native_library_is_built():
     yield
 
 
+def natural_frame():
+    """The reference's own 1920x1080 test image (tests/media/imgs/frame63.jpeg, a data file), decoded with Pillow
+    exactly as tools/make_golden.py did."""
+    from PIL import Image
+    return np.array(Image.open(os.path.join(GOLDEN, "frame63.jpeg")).convert("RGB"))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
@@ -52,7 +60,8 @@ def golden_dir():
 def golden_cases():
     """DCT codec cases."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN)
-                  if f.endswith(".npz") and f != "payload_codecs.npz" and not f.startswith("svd_"))
+                  if f.endswith(".npz") and f not in ("payload_codecs.npz", "frame63_full_digest.npz")
+                  and not f.startswith("svd_"))
 
 
 def svd_golden_cases():

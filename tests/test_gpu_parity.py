@@ -576,3 +576,31 @@ def test_inplace_and_unaligned_frame_pointers(eng):
     c1, b1 = eng.detect(ref, 8, want_bits=True)
     c2, b2 = eng.detect(view, 8, want_bits=True)
     assert torch.equal(c1, c2) and torch.equal(b1, b2)
+
+
+def test_full_natural_1080p_frame(eng):
+    """The reference's own 1920x1080 JPEG frame (chroma-subsampled content: ~15 % of its blocks are chroma-flat,
+    i.e. sign-ambiguous) through the HIP path, against the oracle."""
+    from conftest import natural_frame
+    from offmark.degenerator.de_shuffler import DeShuffler
+    nat = natural_frame()
+    wm = orc.shuffle_generate(P8, (1, 32400), 0)
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(wm)
+    ref = orc.mark_frame(nat, enc)
+    ref_bits = orc.check_frame(ref, orc.DctDecoderOracle(alpha=20)).reshape(-1)
+    marked, counts, bits = eng.embed_detect(cuda(nat[None]), wm, L=8, want_bits=True)
+    mask, n_amb = sign_determined_pixels(nat, wm, 20)
+    assert 0.02 < n_amb / 32400 < 0.5
+    assert_pixels_close(marked[0].cpu().numpy(), ref, mask)
+    c2, b2 = eng.detect(cuda(ref[None]), 8, want_bits=True)
+    assert_bits_close(b2[0].cpu().numpy(), ref_bits, 32400)
+    deg = DeShuffler(key=0).set_shape((8,))
+    assert np.array_equal(deg.degenerate_counts(c2[0].cpu().numpy(), 32400), P8)
+    assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), 32400), P8)
+    # our own marked frame decodes to the same bits as the reference's on the sign-determined blocks
+    det = mask[::8, ::8].reshape(-1)
+    own = bits[0].cpu().numpy()
+    assert (own[det] != ref_bits[det]).sum() <= budget(32400, 5e-3)
+    # and the raw bit-error rate against the embedded watermark is the same as the reference's to within 0.5 %
+    assert abs((own != wm.reshape(-1)).mean() - (ref_bits != wm.reshape(-1)).mean()) < 5e-3

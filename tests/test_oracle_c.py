@@ -47,3 +47,25 @@ def test_c_oracle_threads_give_identical_results():
     a, _ = c_oracle.mark_frames(frames, wm, threads=1)
     b, used = c_oracle.mark_frames(frames, wm, threads=4)
     assert used == 4 and np.array_equal(a, b)
+
+
+def test_full_natural_frame_digests_match_the_reference_run():
+    """The reference's own 1920x1080 JPEG frame: NumPy oracle, C oracle and the reference modules' run
+    (stored as SHA-256 digests by tools/make_golden.py) must all produce the same marked frame and raw bits."""
+    import hashlib
+    from conftest import natural_frame
+    g = np.load(os.path.join(GOLDEN, "frame63_full_digest.npz"))
+    nat = natural_frame()
+    assert nat.shape == (1080, 1920, 3)
+    wm = orc.shuffle_generate(P8, (1, 32400), 0)
+    enc = orc.DctEncoderOracle(alpha=20, promotion="nep50")
+    enc.read_wm(wm)
+    marked = orc.mark_frame(nat, enc)
+    assert hashlib.sha256(marked.tobytes()).digest() == g["marked_sha256"].tobytes()
+    raw = orc.check_frame(marked, orc.DctDecoderOracle(alpha=20, promotion="nep50"))
+    assert hashlib.sha256(raw.astype(np.uint8).tobytes()).digest() == g["raw_bits_sha256"].tobytes()
+    assert abs(np.mean(raw.reshape(-1) != wm.reshape(-1)) - float(g["raw_ber"])) < 1e-12
+    assert np.array_equal(orc.deshuffle(raw, 8, 0), g["degenerated"]) and np.array_equal(g["degenerated"], P8)
+    cm, _ = c_oracle.mark_frames(nat[None], wm, alpha=20, legacy=False)
+    cb, _ = c_oracle.check_frames(cm, alpha=20, legacy=False)
+    assert np.array_equal(cm[0], marked) and np.array_equal(cb[0], raw.reshape(-1))

@@ -122,6 +122,19 @@ def main():
         run_case(f"frame63_crop{n}_L8_k0_a20", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0, 20)
     for n, (y, x) in enumerate([(300, 600), (700, 1200)]):
         run_svd_case(f"frame63_crop{n}", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0)
+    # the whole 1920x1080 natural frame: too large to store its outputs, so store their SHA-256 digests
+    import hashlib
+    enc, dec = DctEncoder(alpha=20), DctDecoder(alpha=20)
+    wm = Shuffler(key=0).generate_wm(P8, enc.wm_capacity(nat.shape))
+    enc.read_wm(wm)
+    marked = Embedder(None, enc, None)._Embedder__mark_frame(nat)
+    raw = dec.decode(cv2.cvtColor(marked.astype(np.float32), cv2.COLOR_BGR2YUV))
+    out = DeShuffler(key=0).set_shape(P8.shape).degenerate(raw)
+    np.savez_compressed(os.path.join(OUT, "frame63_full_digest.npz"), payload=P8, key=np.int64(0), alpha=np.float64(20),
+                        marked_sha256=np.frombuffer(hashlib.sha256(marked.tobytes()).digest(), np.uint8),
+                        raw_bits_sha256=np.frombuffer(hashlib.sha256(raw.astype(np.uint8).tobytes()).digest(), np.uint8),
+                        raw_ber=np.float64(np.mean(raw.reshape(-1) != wm.reshape(-1))), degenerated=out)
+    print(f"frame63_full_digest          1080x1920 raw_ber={np.mean(raw.reshape(-1) != wm.reshape(-1)):.4f} payload_ok={np.array_equal(out, P8)}")
     qr = np.asarray(Image.open("/root/reference/tests/media/wms/qr.jpeg").convert("L"))
     run_case("frame63_crop_qr_k0_a20", np.ascontiguousarray(nat[256:256 + 256, 512:512 + 384]), qr, 0, 20,
              image_payload=True)
