@@ -554,6 +554,17 @@ def test_long_and_oversized_payloads_and_empty_inputs(eng):
     assert b"256-byte aligned" in lib.ofmk_last_error()
 
 
+def test_wm_row_map_is_range_checked_on_the_host(eng):
+    frames = cuda(np.stack([orc.synthetic_frame(64, 96, 1)] * 2))
+    wm = np.stack([orc.shuffle_generate(P8, (96,), 0)] * 2)
+    eng.embed(frames, wm, wm_row=np.array([1, 0]))
+    for bad in (np.array([0, 2]), np.array([-1, 0]), [0, 5]):
+        with pytest.raises(ValueError, match="wm_row"):
+            eng.embed(frames, wm, wm_row=bad)
+    with pytest.raises(ValueError, match="one entry per frame"):
+        eng.embed(frames, wm, wm_row=np.array([0]))
+
+
 def test_inplace_and_unaligned_frame_pointers(eng):
     """In-place marking for both codecs, and frame pointers that are not 8-byte aligned (generic byte path)."""
     import torch

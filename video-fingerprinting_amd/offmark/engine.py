@@ -67,12 +67,20 @@ class DctEngine:
             wm = wm.to(device=self.device, dtype=t.uint8).contiguous()
         return wm
 
-    def _rows(self, wm_row, n):
+    def _rows(self, wm_row, n, n_wm=None):
+        """Per-frame watermark-row map -> device int32 [n].  Host arrays are range-checked here; the kernels
+        index the watermark table with these values unchecked."""
         if wm_row is None:
             return None
         t = self.torch
+        if isinstance(wm_row, (list, tuple)):
+            wm_row = np.asarray(wm_row)
         if isinstance(wm_row, np.ndarray):
+            if n_wm is not None and wm_row.size and (wm_row.min() < 0 or wm_row.max() >= n_wm):
+                raise ValueError(f"wm_row entries must be in [0, {n_wm}); got [{wm_row.min()}, {wm_row.max()}]")
             wm_row = t.from_numpy(wm_row.astype(np.int32))
+        elif n_wm is not None and not wm_row.is_cuda and wm_row.numel() and (int(wm_row.min()) < 0 or int(wm_row.max()) >= n_wm):
+            raise ValueError(f"wm_row entries must be in [0, {n_wm})")
         wm_row = wm_row.to(device=self.device, dtype=t.int32).contiguous()
         if wm_row.numel() != n:
             raise ValueError("wm_row needs one entry per frame")
@@ -85,7 +93,7 @@ class DctEngine:
         n, H, W = self._check_frames(frames, t.uint8)
         N = H * W // 64
         wm = self._wm(wm, N)
-        rows = self._rows(wm_row, n)
+        rows = self._rows(wm_row, n, wm.shape[0])
         if out is None:
             out = t.empty_like(frames)
         cf = self._chunk(n, H, W)
@@ -114,7 +122,7 @@ class DctEngine:
         n, H, W = self._check_frames(frames, t.uint8)
         N = H * W // 64
         wm = self._wm(wm, N)
-        rows = self._rows(wm_row, n)
+        rows = self._rows(wm_row, n, wm.shape[0])
         if out is None:
             out = t.empty_like(frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
@@ -144,7 +152,7 @@ class DctEngine:
         t = self.torch
         n, H, W = self._check_frames(yuv, t.float32)
         wm = self._wm(wm, H * W // 64)
-        rows = self._rows(wm_row, n)
+        rows = self._rows(wm_row, n, wm.shape[0])
         cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], _hip.ptr(rows),
@@ -168,7 +176,7 @@ class DctEngine:
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
-        rows = self._rows(wm_row, n)
+        rows = self._rows(wm_row, n, wm.shape[0])
         if out is None:
             out = t.empty_like(frames)
         _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
@@ -188,7 +196,7 @@ class DctEngine:
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
-        rows = self._rows(wm_row, n)
+        rows = self._rows(wm_row, n, wm.shape[0])
         if out is None:
             out = t.empty_like(frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
