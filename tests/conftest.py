@@ -39,8 +39,8 @@ def _native_library_is_built():
     """The HIP library is built in-tree by __graft_entry__.build(); build it (hipcc cross-compiles without a
     GPU) if a fresh checkout reaches the tests first.  Tests never fall back to anything else."""
     import __graft_entry__ as ge
-    src = os.path.join(ge.CSRC, "offmark_kernels.hip")
-    if not os.path.exists(ge.LIB) or os.path.getmtime(ge.LIB) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(ge.CSRC, f)) for f in os.listdir(ge.CSRC))
+    if not os.path.exists(ge.LIB) or os.path.getmtime(ge.LIB) < newest:
         ge.build()
     yield
 
