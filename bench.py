@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--alpha", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = alternate steps between two HIP streams (own workspace and output buffer each)")
+    ap.add_argument("--onepass", type=int, default=-1, metavar="GRID",
+                    help="DCT codec: use the persistent one-pass embed+verify kernel with GRID workgroups (0 = its default)")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
                     help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
@@ -131,6 +133,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _hip.load()
+    if a.onepass >= 0:
+        lib.ofmk_set_fused_verify(3)
+        lib.ofmk_set_onepass_grid(a.onepass)
 
     n, H, W = a.frames, a.height, a.width
     N = H * W // 64

@@ -152,6 +152,15 @@ void ofmk_timing_disable(void);
  * experimental single-pass variant for ofmk_stage_mark_rgb8, see tools/upper_bound.py.) */
 void ofmk_set_fused_verify(int on);
 
+/* Experimental (round 1): on = 3 makes ofmk_embed_detect_rgb8 use a persistent ONE-PASS kernel that keeps each
+ * block's pixels in registers across the frame-mean dependency (6 instead of 9 B/px of traffic; same results
+ * bit for bit).  ofmk_set_onepass_grid sets its number of workgroups (work is ticketed, so no dispatch order is
+ * assumed; the launcher raises the grid to the number of 256-block tiles of one frame, which must all be in
+ * flight at once, and frames of more than 512 tiles use the two-kernel path).  Its spins are bounded; ofmk_onepass_error copies the time-out flag of the last run to the host
+ * (this call synchronises the device). */
+void ofmk_set_onepass_grid(int workgroups);
+int ofmk_onepass_error(void *workspace, size_t workspace_bytes, int H, int W, int chunk_frames, unsigned int *host_flag);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert sorted(_hip.SYMBOLS) == declared
     assert lib.ofmk_version() == 1
     # pure host-side entry points are safe to call without a GPU
-    assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 32 * 8 + 1024
+    assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 32 * 8 + 16 + 4096
     assert lib.ofmk_workspace_bytes(0, 1080, 1920) == 0 and lib.ofmk_workspace_bytes(1, 4, 1920) == 0
 
 

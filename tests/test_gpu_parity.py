@@ -615,3 +615,34 @@ def test_full_natural_1080p_frame(eng):
     assert (own[det] != ref_bits[det]).sum() <= budget(32400, 5e-3)
     # and the raw bit-error rate against the embedded watermark is the same as the reference's to within 0.5 %
     assert abs((own != wm.reshape(-1)).mean() - (ref_bits != wm.reshape(-1)).mean()) < 5e-3
+
+
+def test_onepass_persistent_kernel_equals_two_kernel_path(eng):
+    """The ticketed one-pass embed+verify kernel (pixels stay in registers across the frame-mean dependency)
+    must reproduce the analyze + fused-mark path bit for bit, for any grid size, and never time out."""
+    import ctypes
+    import torch
+    from offmark import _hip
+    from offmark.synthetic import synthetic_frames
+    lib = _hip.load()
+    for (H, W, n) in [(240, 320, 37), (1080, 1920, 24), (30, 44, 5)]:
+        N = H * W // 64
+        frames = synthetic_frames(n, H, W, seed=900 + H)
+        payloads = np.stack([[int(b) for b in format(s + 1, "08b")] for s in range(4)])
+        wm = np.stack([orc.shuffle_generate(p, (N,), 0) for p in payloads])
+        rows = (np.arange(n) % 4).astype(np.int32)
+        ref_out, ref_counts, ref_bits = eng.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
+        try:
+            for grid in (1, 7, 768, 4096):      # 1 and 7 are raised to the tiles of one frame by the launcher
+                lib.ofmk_set_fused_verify(3)
+                lib.ofmk_set_onepass_grid(grid)
+                out, counts, bits = eng.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
+                torch.cuda.synchronize()
+                ws = eng.workspace(H, W, eng._chunk(n, H, W))
+                flag = ctypes.c_uint(7)
+                _hip.check(lib.ofmk_onepass_error(ws.data_ptr(), ws.numel(), H, W, eng._chunk(n, H, W), ctypes.byref(flag)))
+                assert flag.value == 0, f"spin timed out (grid {grid})"
+                assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(bits, ref_bits), (H, W, grid)
+        finally:
+            lib.ofmk_set_fused_verify(1)
+            lib.ofmk_set_onepass_grid(0)

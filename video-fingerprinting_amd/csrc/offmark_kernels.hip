@@ -48,6 +48,8 @@ using namespace ofmk;
 // ------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
 int g_self_experiment = 0;   // tools/upper_bound.py only
+int g_onepass = 0;           // ofmk_embed_detect_rgb8: 1 = persistent one-pass kernel (ofmk_set_fused_verify(3))
+int g_onepass_grid = 768;    // workgroups of the persistent kernel (3 per CU; raised to tiles-per-frame if smaller)
 int g_fuse_verify = 1;    // ofmk_embed_detect_rgb8: 1 = fused mark+analyze kernel, 0 = separate kernels
 
 // Optional per-launch HIP-event timing (bench.py): events are created by ofmk_timing_enable(),
@@ -90,21 +92,23 @@ struct Workspace {
     float *delta;    // [frames][nblk]
     unsigned long long *ysum;    // mean accumulators of the frames analyze() saw
     unsigned long long *ysum2;   // ... of the marked frames (fused mark+verify kernel)
+    unsigned int *ctl;           // one-pass kernel: [0] ticket, [1] error, then done[frames], ready[frames]
+    unsigned long long *mean_bits;   // one-pass kernel: published frame means [frames]
     int frames;      // chunk capacity
     size_t plane;    // frames * nblk
 };
 
 size_t per_frame_bytes(int H, int W) {
     const size_t nblk = (size_t)(H / 8) * (W / 8);
-    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8;
+    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8 + 16;
 }
 
 int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out) {
     if (!ws) return fail(OFMK_E_ARG, "workspace is null%s");
     if ((uintptr_t)ws % 256) return fail(OFMK_E_ARG, "workspace must be 256-byte aligned%s");
     const size_t per = per_frame_bytes(H, W);
-    if (bytes < per + 1024) return fail(OFMK_E_WORKSPACE, "workspace smaller than ofmk_workspace_bytes(1, H, W)%s");
-    size_t cap = (bytes - 1024) / per;
+    if (bytes < per + 4096) return fail(OFMK_E_WORKSPACE, "workspace smaller than ofmk_workspace_bytes(1, H, W)%s");
+    size_t cap = (bytes - 4096) / per;    // 4096: room for the 256-byte alignment of the seven carved arrays
     if (want_frames > 0 && (size_t)want_frames < cap) cap = want_frames;
     if (cap > (size_t)kMaxChunk) cap = kMaxChunk;
     const size_t nblk = (size_t)(H / 8) * (W / 8);
@@ -118,6 +122,10 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     out.ysum = reinterpret_cast<unsigned long long *>(p);
     p += align256(cap * kSlots * 8);
     out.ysum2 = reinterpret_cast<unsigned long long *>(p);
+    p += align256(cap * kSlots * 8);
+    out.ctl = reinterpret_cast<unsigned int *>(p);          // (2 * cap + 2) uints
+    p += align256((2 * cap + 2) * sizeof(unsigned int));
+    out.mean_bits = reinterpret_cast<unsigned long long *>(p);   // cap u64
     return OFMK_OK;
 }
 
@@ -197,6 +205,47 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
             if (al) hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
             else hipLaunchKernelGGL((mark_rgb8_kernel<false, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
         }
+    }
+    HIP_TRY(hipGetLastError());
+    if (in != out && (H % 8 || W % 8)) {
+        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
+        HIP_TRY(hipGetLastError());
+    }
+    return OFMK_OK;
+}
+
+// One-pass embed + verify: leaves the marked frames in `out`, their records in ws.rec and their mean
+// accumulators in ws.ysum2 (as the fused mark kernel does), ready for finalize_detect(after_fused_mark).
+int launch_onepass_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
+                        double alpha, const Workspace &ws, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)n * kSlots * 8, s));
+    HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
+    HIP_TRY(hipMemsetAsync(ws.ctl, 0, (size_t)(2 * ws.frames + 2) * sizeof(unsigned int), s));
+    const Geom g = make_geom(H, W, ws);
+    MarkArgs m;
+    m.rec = nullptr;
+    m.ysum = nullptr;
+    m.wm = wm;
+    m.wm_row = wm_row;
+    m.N = (int)((long long)H * W / 64);
+    m.alpha = alpha;
+    OnePassCtl ctl;
+    ctl.ticket = ws.ctl;
+    ctl.error = ws.ctl + 1;
+    ctl.done = ws.ctl + 2;
+    ctl.ready = ws.ctl + 2 + ws.frames;
+    ctl.mean_bits = ws.mean_bits;
+    ctl.tiles_per_frame = (g.nblk + kThreads - 1) / kThreads;
+    ctl.total_tiles = ctl.tiles_per_frame * n;
+    // A workgroup holds ONE tile while it waits for its frame, so a frame only completes if at least
+    // tiles_per_frame workgroups run at once (the caller checked that against the residency limit).
+    int grid = g_onepass_grid < ctl.tiles_per_frame ? ctl.tiles_per_frame : g_onepass_grid;
+    if (grid > ctl.total_tiles) grid = ctl.total_tiles;
+    const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
+    {
+        ScopedTiming timing(KIND_MARK_FUSED, s);
+        if (al) hipLaunchKernelGGL(embed_onepass_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.ysum, ws.rec, ws.ysum2, ctl);
+        else hipLaunchKernelGGL(embed_onepass_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.ysum, ws.rec, ws.ysum2, ctl);
     }
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
@@ -322,10 +371,24 @@ const char *ofmk_last_error(void) { return g_err; }
 
 size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W) {
     if (frames_in_flight < 1 || H < 8 || W < 8) return 0;
-    return per_frame_bytes(H, W) * (size_t)frames_in_flight + 1024;
+    return per_frame_bytes(H, W) * (size_t)frames_in_flight + 4096;
 }
 
-void ofmk_set_fused_verify(int on) { g_fuse_verify = on ? 1 : 0; g_self_experiment = on == 2 ? 1 : 0; }
+void ofmk_set_fused_verify(int on) {
+    g_fuse_verify = on ? 1 : 0;
+    g_self_experiment = on == 2 ? 1 : 0;
+    g_onepass = on == 3 ? 1 : 0;
+}
+
+void ofmk_set_onepass_grid(int workgroups) { g_onepass_grid = workgroups > 0 ? workgroups : 768; }
+
+int ofmk_onepass_error(void *workspace, size_t workspace_bytes, int H, int W, int chunk_frames, unsigned int *host_flag) {
+    Workspace ws;
+    int rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(host_flag, ws.ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    return OFMK_OK;
+}
 
 int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                     const int32_t *wm_row, double alpha, int chunk_frames, void *workspace, size_t workspace_bytes,
@@ -369,7 +432,13 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
     if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if (g_fuse_verify) {
+        // one-pass needs every tile of a frame in flight at once: 2 workgroups per CU are always resident
+        // (150 VGPRs -> 3), so frames of up to 512 tiles (131 072 blocks, e.g. 4K) qualify
+        if (g_onepass && (((H / 8) * (W / 8) + kThreads - 1) / kThreads) <= 512) {
+            const size_t fo = (size_t)f0 * H * W * 3;
+            if ((rc = launch_onepass_rgb8(in + fo, out + fo, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, s))) return rc;
+            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
+        } else if (g_fuse_verify) {
             if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, s))) return rc;
             if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
         } else {
