@@ -92,8 +92,8 @@ struct Workspace {
     float *delta;    // [frames][nblk]
     unsigned long long *ysum;    // mean accumulators of the frames analyze() saw
     unsigned long long *ysum2;   // ... of the marked frames (fused mark+verify kernel)
-    unsigned int *ctl;           // one-pass kernel: [0] ticket, [1] error, then done[frames], ready[frames]
-    unsigned long long *mean_bits;   // one-pass kernel: published frame means [frames]
+    unsigned int *ctl;           // one-pass kernel: [0] ticket, [1] error
+    unsigned long long *mean_bits;   // one-pass kernel: acc[frames] then published means [frames]
     int frames;      // chunk capacity
     size_t plane;    // frames * nblk
 };
@@ -123,9 +123,9 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     p += align256(cap * kSlots * 8);
     out.ysum2 = reinterpret_cast<unsigned long long *>(p);
     p += align256(cap * kSlots * 8);
-    out.ctl = reinterpret_cast<unsigned int *>(p);          // (2 * cap + 2) uints
-    p += align256((2 * cap + 2) * sizeof(unsigned int));
-    out.mean_bits = reinterpret_cast<unsigned long long *>(p);   // cap u64
+    out.ctl = reinterpret_cast<unsigned int *>(p);          // 2 uints
+    p += 256;
+    out.mean_bits = reinterpret_cast<unsigned long long *>(p);   // 2 * cap u64
     return OFMK_OK;
 }
 
@@ -218,9 +218,8 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
 // accumulators in ws.ysum2 (as the fused mark kernel does), ready for finalize_detect(after_fused_mark).
 int launch_onepass_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
                         double alpha, const Workspace &ws, hipStream_t s) {
-    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)n * kSlots * 8, s));
     HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
-    HIP_TRY(hipMemsetAsync(ws.ctl, 0, (size_t)(2 * ws.frames + 2) * sizeof(unsigned int), s));
+    HIP_TRY(hipMemsetAsync(ws.ctl, 0, 256 + (size_t)2 * ws.frames * sizeof(unsigned long long), s));   // ctl, acc, means
     const Geom g = make_geom(H, W, ws);
     MarkArgs m;
     m.rec = nullptr;
@@ -232,9 +231,8 @@ int launch_onepass_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, co
     OnePassCtl ctl;
     ctl.ticket = ws.ctl;
     ctl.error = ws.ctl + 1;
-    ctl.done = ws.ctl + 2;
-    ctl.ready = ws.ctl + 2 + ws.frames;
-    ctl.mean_bits = ws.mean_bits;
+    ctl.acc = ws.mean_bits;
+    ctl.mean_bits = ws.mean_bits + ws.frames;
     ctl.tiles_per_frame = (g.nblk + kThreads - 1) / kThreads;
     ctl.total_tiles = ctl.tiles_per_frame * n;
     // A workgroup holds ONE tile while it waits for its frame, so a frame only completes if at least
@@ -244,8 +242,8 @@ int launch_onepass_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, co
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
     {
         ScopedTiming timing(KIND_MARK_FUSED, s);
-        if (al) hipLaunchKernelGGL(embed_onepass_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.ysum, ws.rec, ws.ysum2, ctl);
-        else hipLaunchKernelGGL(embed_onepass_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.ysum, ws.rec, ws.ysum2, ctl);
+        if (al) hipLaunchKernelGGL(embed_onepass_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2, ctl);
+        else hipLaunchKernelGGL(embed_onepass_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2, ctl);
     }
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
