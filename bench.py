@@ -306,7 +306,10 @@ def main():
 
     base = None
     if world == 1 and not a.no_cpu_baseline and a.codec == "dct":
-        base = cpu_baseline(frames[:96].cpu().numpy(), wm, a.alpha, a.cpu_seconds)
+        try:
+            base = cpu_baseline(frames[:96].cpu().numpy(), wm, a.alpha, a.cpu_seconds)
+        except Exception as exc:                       # e.g. no C compiler on the box: report, do not lose the GPU line
+            base = dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"cpu baseline failed: {exc!r}")
 
     path_gbps = fps * 9 * H * W / 1e9                                   # 9 B/px per embed+detect frame
     line = {
