@@ -68,6 +68,14 @@ int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha
                      int32_t *counts, uint8_t *bits,
                      int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- soft-decision read-out (BUILD EXTENSION, not reference semantics) -------------
+ * soft: device int64 [n][L]; soft[f][i] = sum over blocks c with c mod L == i of round(-cos(pi*C21/step) * 2^14):
+ * positive means position i reads as 1, the magnitude is a confidence.  Sums over frames of a segment can be
+ * added before thresholding at 0 (offmark.dist.vote.soft_vote).  The reference's hard decision stays the
+ * default everywhere. */
+int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha, long long *soft,
+                          int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- embed then detect the produced frames, chunk by chunk (mark + verify) ---------------
  * The shape of tests/mark_video_to_hls.py:356-389 (verify every marked copy).  Same results as
  * ofmk_embed_rgb8 followed by ofmk_detect_rgb8 on `out`; the detect pass of a chunk runs while

@@ -646,3 +646,39 @@ def test_onepass_persistent_kernel_equals_two_kernel_path(eng):
         finally:
             lib.ofmk_set_fused_verify(1)
             lib.ofmk_set_onepass_grid(0)
+
+
+def test_soft_decision_extension(eng):
+    """Optional soft read-out (build extension): on clean frames it agrees with the hard decision
+    and with a host evaluation of the same formula; under heavy noise, adding soft sums over the frames of a
+    segment recovers at least as many segments as the reference's per-frame hard vote."""
+    import torch
+    from offmark import fingerprint as fp
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.dist.vote import soft_vote, vote_segments
+    from offmark.synthetic import synthetic_frames
+    H, W, S, F = 240, 320, 8, 10
+    N = H * W // 64
+    frames = synthetic_frames(S * F, H, W, seed=8000)
+    payloads = np.stack([fp.payload_for_segment(s + 1) for s in range(S)])
+    wm = np.stack([orc.shuffle_generate(p, (N,), 0) for p in payloads])
+    seg = np.repeat(np.arange(S), F)
+    marked = eng.embed(frames, wm, wm_row=seg.astype(np.int32))
+    deg = DeShuffler(key=0).set_shape((8,))
+    soft = eng.detect_soft(marked, 8).cpu().numpy()
+    # same formula on the host from the debug planes of one frame
+    d = eng.debug_planes(marked[0], alpha=20)
+    r = d["c21_pre"].astype(np.float64) / d["step"]
+    sv = np.rint(-np.cos(np.pi * r) * 16384).astype(np.int64).reshape(-1)
+    assert np.abs(soft[0] - np.array([sv[i::8].sum() for i in range(8)])).max() <= 8 * 2        # rounding of cospi
+    clean = soft_vote(soft, deg.payload_idx, seg)
+    assert all(np.array_equal(clean[s], payloads[s]) for s in range(S))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    noisy = (marked.float() + 9.0 * torch.randn(marked.shape, device="cuda", generator=g)).round().clamp(0, 255).to(torch.uint8)
+    counts, _ = eng.detect(noisy, 8)
+    hard = vote_segments(deg.degenerate_counts(counts.cpu().numpy(), N), seg)
+    softv = soft_vote(eng.detect_soft(noisy, 8).cpu().numpy(), deg.payload_idx, seg)
+    n_hard = sum(np.array_equal(hard[s][0], payloads[s]) for s in range(S))
+    n_soft = sum(np.array_equal(softv[s], payloads[s]) for s in range(S))
+    print(f"noise sigma 9: hard per-frame vote recovers {n_hard}/{S} segments, summed soft decision {n_soft}/{S}")
+    assert n_soft >= n_hard

@@ -418,6 +418,31 @@ int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha
     return OFMK_OK;
 }
 
+// Build extension, not reference semantics: per payload position the sum over the frame's blocks
+// of -cos(pi * C21/step) in 2^14 fixed point (positive = the position reads as 1).  One histogram per call, so
+// it is a separate entry point from the hard-decision counts.
+int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha, long long *soft, int chunk_frames,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_dims(n, H, W);
+    if (rc) return rc;
+    if (!in || !soft) return fail(OFMK_E_ARG, "null pointer%s");
+    if (L < 1) return fail(OFMK_E_ARG, "payload length L must be >= 1%s");
+    Workspace ws;
+    if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(soft, 0, (size_t)n * L * sizeof(long long), s));
+    const size_t fs = (size_t)H * W * 3;
+    for (int f0 = 0; f0 < n; f0 += ws.frames) {
+        const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
+        if ((rc = launch_analyze(in + (size_t)f0 * fs, SRC_RGB8, cf, H, W, ws, s))) return rc;
+        FinArgs a = fin_base(ws, H, W, alpha);
+        a.L = L;
+        a.soft = soft + (size_t)f0 * L;
+        if ((rc = launch_finalize(a, cf, s))) return rc;
+    }
+    return OFMK_OK;
+}
+
 int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                            const int32_t *wm_row, double alpha, int L, int32_t *counts, uint8_t *bits,
                            int chunk_frames, void *workspace, size_t workspace_bytes, void *stream) {

@@ -19,7 +19,7 @@ SYMBOLS = (
     "ofmk_stage_analyze_rgb8", "ofmk_stage_mark_rgb8", "ofmk_hbm_copy", "ofmk_set_fused_verify",
     "ofmk_timing_enable", "ofmk_timing_collect", "ofmk_timing_disable", "ofmk_payloads_from_counts",
     "ofmk_svd_embed_rgb8", "ofmk_svd_detect_rgb8", "ofmk_svd_embed_detect_rgb8", "ofmk_svd_encode_yuv32f",
-    "ofmk_svd_decode_yuv32f", "ofmk_set_onepass_grid", "ofmk_onepass_error",
+    "ofmk_svd_decode_yuv32f", "ofmk_set_onepass_grid", "ofmk_onepass_error", "ofmk_detect_soft_rgb8",
 )
 
 
@@ -74,6 +74,8 @@ def load():
     for name in ("ofmk_svd_embed_rgb8", "ofmk_svd_detect_rgb8", "ofmk_svd_embed_detect_rgb8",
                  "ofmk_svd_encode_yuv32f", "ofmk_svd_decode_yuv32f"):
         getattr(lib, name).restype = i32
+    lib.ofmk_detect_soft_rgb8.argtypes = [vp, i32, i32, i32, i32, f64, vp, i32, vp, sz, vp]
+    lib.ofmk_detect_soft_rgb8.restype = i32
     lib.ofmk_set_onepass_grid.argtypes = [i32]
     lib.ofmk_set_onepass_grid.restype = None
     lib.ofmk_onepass_error.argtypes = [vp, sz, i32, i32, i32, C.POINTER(C.c_uint)]

@@ -100,3 +100,18 @@ def vote_segments(patterns, segment_ids):
     rows = np.asarray(patterns)
     seg = np.asarray(segment_ids)
     return {int(s): vote(rows[seg == s]) for s in np.unique(seg)}
+
+
+def soft_vote(soft_sums, perm, segment_ids=None):
+    """Build extension (not reference semantics): combine per-frame soft sums [n, L] (offmark's
+    DctEngine.detect_soft) by ADDING them over the frames of each segment, undo the key permutation and read
+    each payload position by the sign of its total.  Returns {segment: payload uint8 [L]} (segment 0 if none)."""
+    s = np.asarray(soft_sums, dtype=np.int64)
+    seg = np.zeros(len(s), dtype=np.int64) if segment_ids is None else np.asarray(segment_ids)
+    out = {}
+    for k in np.unique(seg):
+        total = s[seg == k].sum(axis=0)
+        payload = np.empty_like(total)
+        payload[np.asarray(perm)] = total
+        out[int(k)] = (payload > 0).astype(np.uint8)
+    return out

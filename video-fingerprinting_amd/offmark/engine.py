@@ -116,6 +116,17 @@ class DctEngine:
                                              _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
         return counts, bits
 
+    def detect_soft(self, frames, L, alpha=20):
+        """Build extension (not reference semantics): per-position soft sums, int64 [n, L]; > 0 reads as 1."""
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        soft = t.empty((n, L), dtype=t.int64, device=self.device)
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_detect_soft_rgb8(frames.data_ptr(), n, H, W, int(L), float(alpha), soft.data_ptr(), cf,
+                                                  ws.data_ptr(), ws.numel(), _hip.current_stream()))
+        return soft
+
     def embed_detect(self, frames, wm, L, alpha=20, wm_row=None, out=None, want_bits=False):
         """Mark, then read back the marked frames chunk by chunk (mark + verify)."""
         t = self.torch
