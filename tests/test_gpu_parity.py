@@ -682,3 +682,30 @@ def test_soft_decision_extension(eng):
     n_soft = sum(np.array_equal(softv[s], payloads[s]) for s in range(S))
     print(f"noise sigma 9: hard per-frame vote recovers {n_hard}/{S} segments, summed soft decision {n_soft}/{S}")
     assert n_soft >= n_hard
+
+
+def test_grayscale_content_where_every_block_is_sign_ambiguous(eng):
+    """R = G = B video: U is float rounding noise around 0.5 everywhere, so EVERY block's C21 sign is undefined
+    (see the module docstring).  The quantised magnitude, the decoded bits and the payload must still agree
+    with the oracle; pixels may differ by the sign of the +-step pattern."""
+    from offmark.degenerator.de_shuffler import DeShuffler
+    g = orc.synthetic_frame(240, 320, 1001)[:, :, 1]
+    frame = np.repeat(g[:, :, None], 3, axis=2)
+    wm = orc.shuffle_generate(P8, (1, 1200), 0)
+    dbg = oracle_embed_debug(frame, wm, 20)
+    assert (np.abs(dbg["c21_pre"]) <= C21_TOL).mean() > 0.99
+    d = eng.debug_planes(cuda(frame), alpha=20, wm=wm)
+    both_zero = (dbg["c21_pre"] == 0) & (d["c21_pre"] == 0)
+    mag_ok = np.abs(np.abs(d["c21_post"]) - np.abs(dbg["c21_post"])) <= 2e-3
+    zero_vs_noise = ((dbg["c21_pre"] == 0) != (d["c21_pre"] == 0))
+    assert (~(mag_ok | zero_vs_noise)).sum() == 0 and zero_vs_noise.sum() <= budget(1200, 2e-2)
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(wm)
+    ref = orc.mark_frame(frame, enc)
+    ref_bits = orc.check_frame(ref, orc.DctDecoderOracle(alpha=20)).reshape(-1)
+    marked, counts, bits = eng.embed_detect(cuda(frame[None]), wm, L=8, want_bits=True)
+    deg = DeShuffler(key=0).set_shape((8,))
+    assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), 1200), P8)
+    assert np.array_equal(orc.deshuffle(ref_bits, 8, 0), P8)
+    assert (bits[0].cpu().numpy() != ref_bits).sum() <= budget(1200, 2e-2)
+    assert np.abs(marked[0].cpu().numpy().astype(int) - ref.astype(int)).max() <= 2 * 60     # at most a flipped +-step pattern
