@@ -63,3 +63,29 @@ def test_payload_means_slice_lengths(L, N):
             assert means[i] == 1.0
         else:
             assert np.isnan(means[i])
+
+
+# ---- C oracle == NumPy oracle on random small frames (sizes need not be multiples of 8) ------------------
+import c_oracle  # noqa: E402
+
+
+@settings(max_examples=40, deadline=None)
+@given(h=st.integers(8, 40), w=st.integers(8, 56), seed=st.integers(0, 10**6), alpha=st.sampled_from([5, 10, 20, 33.5]),
+       legacy=st.booleans(), flat=st.booleans())
+def test_c_oracle_matches_numpy_oracle_on_random_frames(h, w, seed, alpha, legacy, flat):
+    rng = np.random.default_rng(seed)
+    if flat:                                  # piecewise-constant content: exact-zero C21 and mask edge branches
+        frame = np.kron(rng.integers(0, 256, size=((h + 7) // 8, (w + 7) // 8, 3)), np.ones((8, 8, 1)))[:h, :w].astype(np.uint8)
+    else:
+        frame = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    n = h * w // 64
+    wm = rng.integers(0, 2, size=(1, max(n, 1)))
+    promo = "legacy" if legacy else "nep50"
+    enc = orc.DctEncoderOracle(alpha=alpha, promotion=promo)
+    enc.read_wm(wm)
+    ref = orc.mark_frame(frame, enc)
+    got, _ = c_oracle.mark_frames(frame[None], wm, alpha=alpha, legacy=legacy)
+    assert np.array_equal(got[0], ref)
+    bits_ref = orc.check_frame(ref, orc.DctDecoderOracle(alpha=alpha, promotion=promo)).reshape(-1)
+    bits, _ = c_oracle.check_frames(ref[None], alpha=alpha, legacy=legacy)
+    assert np.array_equal(bits[0], bits_ref)
