@@ -44,8 +44,8 @@ def _worker(rank, world, port, n_total, ragged, q):
         dist.destroy_process_group()
 
 
-def _run(n_total, ragged):
-    world, port = 2, _free_port()
+def _run(n_total, ragged, world=2):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, ragged, q)) for r in range(world)]
@@ -55,7 +55,7 @@ def _run(n_total, ragged):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert out[0] == out[1]                                   # identical vote on every rank
+    assert all(out[r] == out[0] for r in range(world))        # identical vote on every rank
     for seg, (pattern, freq) in out[0].items():
         assert pattern == [int(b) for b in format(seg + 1, "08b")] and freq >= 0.5
     return out
@@ -67,3 +67,7 @@ def test_equal_shards_all_gather_and_vote():
 
 def test_ragged_shards_all_gather_and_vote():
     _run(37, ragged=True)
+
+
+def test_four_ranks_ragged():
+    _run(50, ragged=True, world=4)
