@@ -36,14 +36,15 @@ class DctEngine:
 
     # -- scratch ------------------------------------------------------------------------------
     def workspace(self, H: int, W: int, frames: int):
-        key = (H, W, frames)
-        ws = self._ws.get(key)
-        if ws is None:
-            nbytes = self.lib.ofmk_workspace_bytes(frames, H, W)
-            if nbytes == 0:
-                raise _hip.HipError(f"bad frame size {H}x{W}")
+        """Scratch for `frames` frames in flight.  One buffer per frame size is kept and only ever grows: the
+        library sizes its chunks to min(chunk_frames, what fits), so a larger buffer serves smaller batches."""
+        nbytes = self.lib.ofmk_workspace_bytes(frames, H, W)
+        if nbytes == 0:
+            raise _hip.HipError(f"bad frame size {H}x{W}")
+        ws = self._ws.get((H, W))
+        if ws is None or ws.numel() < nbytes:
             ws = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
-            self._ws = {key: ws}          # keep one; sizes rarely change within a job
+            self._ws = {(H, W): ws}       # keep one size; frame sizes rarely change within a job
         return ws
 
     def _chunk(self, n, H, W, bytes_per_sample=1):
