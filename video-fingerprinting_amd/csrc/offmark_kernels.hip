@@ -172,7 +172,8 @@ int launch_analyze(const void *frames, int src, int n, int H, int W, const Works
 }
 
 int launch_finalize(FinArgs a, int n, hipStream_t s) {
-    const unsigned gx = (unsigned)((a.N + kThreads - 1) / kThreads);
+    const int per_wg = kThreads * kFinItems;
+    const unsigned gx = (unsigned)((a.N + per_wg - 1) / per_wg);
     ScopedTiming timing(KIND_FINALIZE, s);
     hipLaunchKernelGGL(finalize_kernel, dim3(gx, (unsigned)n), dim3(kThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
