@@ -158,9 +158,12 @@ def main():
     side = torch.cuda.Stream()                    # all-gather + download: off the compute stream, so a slow
     handoff = [torch.cuda.Event() for _ in range(2)]   # peer never stalls this rank's next step
 
+    host_s = {"enqueue": 0.0, "vote": 0.0}     # host-side seconds spent issuing work / voting (not waiting)
+
     def enqueue(k):
         """GPU half of step k: embed, detect the marked frames, per-frame payloads; then, on a side stream,
         the all-gather of the payloads and their download into pinned memory."""
+        t_in = time.perf_counter()
         lane = lanes[k % len(lanes)]
         e = lane["eng"]
         with torch.cuda.stream(lane["stream"]):
@@ -179,13 +182,17 @@ def main():
                 everyone = gather_payloads(mine, equal_shards=True)      # RCCL all-gather (N > 1)
             host[k & 1].copy_(everyone, non_blocking=True)
             ready[k & 1].record()
+        host_s["enqueue"] += time.perf_counter() - t_in
         return mine
 
     def finish(k):
         """Host half of step k: the reference's cross-frame Counter vote, once its payloads have landed.
         It runs while the GPU is already working on step k+1 (double-buffered)."""
         ready[k & 1].synchronize()
-        return vote_segments(host[k & 1].numpy(), seg_ids)
+        t_in = time.perf_counter()
+        v = vote_segments(host[k & 1].numpy(), seg_ids)
+        host_s["vote"] += time.perf_counter() - t_in
+        return v
 
     def run(steps):
         votes, mine = None, None
@@ -229,10 +236,12 @@ def main():
     if use_events:
         _hip.check(lib.ofmk_timing_enable(launches_per_step * a.steps + 16, 1 << KINDS.index(DOMINANT)))
     fence()
+    host_s.update(enqueue=0.0, vote=0.0)
     t0 = time.perf_counter()
     votes, mine = run(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in host_s.items()}
     if world > 1:
         t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,6 +348,7 @@ def main():
                  "frac_of_peak": round(path_gbps / (HBM_PEAK_GBPS * world), 4),
                  "frac_of_measured_copy": round(path_gbps / (copy_gbps * world), 4)},
         "hbm_copy_GBps": round(copy_gbps, 1),
+        "host_ms_per_step": host_ms,            # rank 0's CPU time issuing a step / voting on one; must stay < ms_per_step
         "cpu_baseline": base,
     }
     line.update(extra)
