@@ -217,8 +217,12 @@ def main():
                 _, c1, _ = lane["eng"].embed_detect(frames[:1], wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=lane["out"][:1])
             else:
                 _, c1, _ = lane["eng"].svd_embed_detect(frames[:1], wm_dev, L=PAYLOAD.size, scale=15, out=lane["out"][:1])
-            lane["eng"].payloads(c1, N, perm_dev)
+            p1 = lane["eng"].payloads(c1, N, perm_dev)
     torch.cuda.synchronize()
+    if world > 1:                                   # first collective on the side stream: RCCL sets its channels up here
+        with torch.cuda.stream(side):
+            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=True)
+        torch.cuda.synchronize()
     if a.warmup:
         run(a.warmup)
     launches_per_step = 5 * ((n + chunk - 1) // chunk)      # upper bound (4 with the fused verify kernel)

@@ -709,3 +709,58 @@ def test_grayscale_content_where_every_block_is_sign_ambiguous(eng):
     assert np.array_equal(orc.deshuffle(ref_bits, 8, 0), P8)
     assert (bits[0].cpu().numpy() != ref_bits).sum() <= budget(1200, 2e-2)
     assert np.abs(marked[0].cpu().numpy().astype(int) - ref.astype(int)).max() <= 2 * 60     # at most a flipped +-step pattern
+
+
+def _content(rng, H, W, kind):
+    """Frame contents that steer the masks and the quantiser into their different branches."""
+    if kind == "synthetic":
+        return orc.synthetic_frame(H, W, int(rng.integers(1 << 30)))
+    if kind == "noise":
+        return rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    if kind == "flat":
+        return np.broadcast_to(rng.integers(0, 256, 3, dtype=np.uint8), (H, W, 3)).copy()
+    if kind == "dark":                                 # block means below 15 / 25: the luminance mask's dark steps
+        return rng.integers(0, 40, (H, W, 3), dtype=np.uint8)
+    if kind == "bright":                               # saturation: np.clip on the way back to u8
+        return rng.integers(235, 256, (H, W, 3), dtype=np.uint8)
+    if kind == "ramp":                                 # smooth gradients, exact zeros and tiny coefficients
+        y, x = np.mgrid[0:H, 0:W]
+        return np.stack([(x * 255 // max(W - 1, 1)), (y * 255 // max(H - 1, 1)), ((x + y) % 256)], -1).astype(np.uint8)
+    if kind == "checker":                              # maximal texture energy
+        y, x = np.mgrid[0:H, 0:W]
+        v = (((x // 2) + (y // 3)) % 2 * 255).astype(np.uint8)
+        return np.stack([v, 255 - v, v], -1)
+    raise ValueError(kind)
+
+
+def test_random_shapes_contents_and_strengths(eng):
+    """Seeded sweep over frame sizes (multiples of 8 or not, 16-byte aligned rows or not), batch sizes, alphas,
+    payload lengths and frame contents; every frame against the oracle, embed and detect."""
+    rng = np.random.default_rng(4242)
+    kinds = ["synthetic", "noise", "flat", "dark", "bright", "ramp", "checker"]
+    for trial in range(28):
+        H, W = int(rng.integers(8, 150)), int(rng.integers(8, 200))
+        if trial % 4 == 0:
+            W = (W // 16 + 1) * 16                      # aligned fast path
+        n = int(rng.integers(1, 5))
+        alpha = float(rng.choice([5.0, 10.0, 20.0, 33.5]))
+        L = int(rng.choice([2, 5, 8, 13]))
+        payload = rng.integers(0, 2, L)
+        N, nblk = H * W // 64, (H // 8) * (W // 8)
+        wm = orc.shuffle_generate(payload, (1, N), 3)
+        frames = np.stack([_content(rng, H, W, kinds[(trial + k) % len(kinds)]) for k in range(n)])
+        got, counts, bits = eng.embed_detect(cuda(frames), wm, L=L, alpha=alpha, want_bits=True)
+        got = got.cpu().numpy()
+        for k in range(n):
+            enc = orc.DctEncoderOracle(alpha=alpha)
+            enc.read_wm(wm)
+            ref = orc.mark_frame(frames[k], enc)
+            mask, _ = sign_determined_pixels(frames[k], wm, alpha)
+            assert_pixels_close(got[k], ref, mask)
+            ref_bits = orc.check_frame(ref, orc.DctDecoderOracle(alpha=alpha))
+            _, b2 = eng.detect(cuda(ref[None]), L, alpha=alpha, want_bits=True)
+            assert_bits_close(b2[0].cpu().numpy(), ref_bits, nblk)
+        # the fused verify (bits of the frames the engine itself wrote) agrees with a separate detect call
+        c3, b3 = eng.detect(cuda(got), L, alpha=alpha, want_bits=True)
+        assert np.array_equal(c3.cpu().numpy(), counts.cpu().numpy())
+        assert np.array_equal(b3.cpu().numpy(), bits.cpu().numpy())

@@ -144,3 +144,31 @@ def test_mark_py_and_detect_py_logic_literally(eng):
     assert bits.dtype == np.float64 and bits.shape == ref_bits.shape and (bits != ref_bits).sum() <= 6
     with pytest.raises(NotImplementedError):
         DwtDctSvdEncoder(scales=[15, 15, 0])
+
+
+def test_svd_random_shapes_and_contents(eng):
+    """Seeded sweep over frame sizes, batch sizes and contents, every frame against the oracle."""
+    from test_gpu_parity import _content
+    rng = np.random.default_rng(777)
+    kinds = ["synthetic", "noise", "dark", "bright", "ramp", "checker", "flat"]
+    for trial in range(20):
+        H, W = int(rng.integers(8, 150)), int(rng.integers(8, 200))
+        if trial % 4 == 0:
+            W = (W // 16 + 1) * 16
+        n = int(rng.integers(1, 4))
+        N, nblk = H * W // 64, (H // 8) * (W // 8)
+        wm = orc.shuffle_generate(rng.integers(0, 2, 8), (1, N), 1)
+        frames = np.stack([_content(rng, H, W, kinds[(trial + k) % len(kinds)]) for k in range(n)])
+        got, counts, bits = eng.svd_embed_detect(cuda(frames), wm, 8, want_bits=True)
+        got = got.cpu().numpy()
+        for k in range(n):
+            enc = orc.DwtDctSvdEncoderOracle()
+            enc.read_wm(wm)
+            ref = orc.mark_frame(frames[k], enc)
+            mask, _ = determined_pixels(frames[k], wm)
+            assert_pixels_close(got[k], ref, mask)
+            ref_bits = orc.check_frame(ref, orc.DwtDctSvdDecoderOracle())
+            _, b2 = eng.svd_detect(cuda(ref[None]), 8, want_bits=True)
+            assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(nblk, 5e-3), (trial, k)
+        c3, b3 = eng.svd_detect(cuda(got), 8, want_bits=True)
+        assert np.array_equal(c3.cpu().numpy(), counts.cpu().numpy()) and np.array_equal(b3.cpu().numpy(), bits.cpu().numpy())
