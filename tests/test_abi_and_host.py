@@ -4,7 +4,6 @@ plumbing works with an in-memory reader/writer, and the product path refuses to 
 import os
 import re
 import subprocess
-import sys
 
 import numpy as np
 import pytest

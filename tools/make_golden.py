@@ -13,7 +13,6 @@ The container's numpy is 2.x, so the captured texture-mask values follow NEP 50 
 import logging
 import os
 import sys
-import types
 
 import numpy as np
 

@@ -10,7 +10,6 @@ the backend is "nccl", gloo on CPU for tests), then the same Counter vote on eve
 from __future__ import annotations
 
 import os
-from collections import Counter
 
 import numpy as np
 
