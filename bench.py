@@ -8,16 +8,18 @@ Workload at N=1: BASELINE.json configs[1] -- 300 synthetic 1080p frames, payload
 [0,1,1,0,0,1,0,1], Shuffler(key=0), alpha=20.  With N ranks every rank holds its own 300 frames
 (weak scaling, frames shard with no data-path collective).
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 100 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused mark+verify kernel:
-it re-reads each frame, writes the marked frame and analyzes it); its launch durations come from
-HIP events the library records on the launch stream around every one of its launches DURING the
-timed steps.  Bracketing every kernel costs ~7 % of throughput, so the other kernels' durations
-(`kernels`) come from a short extra pass after the timed region.  `cpu_baseline` is the NumPy
-oracle (a port of the reference algorithm; OpenCV is not installed) on one host core.
+it re-reads each frame, writes the marked frame and analyzes it).  Launch durations (`kernels`) come
+from HIP event pairs the library attaches to every kernel dispatch of the timed steps
+(hipExtLaunchKernelGGL start/stop events on the launch stream: the dispatch's own timestamps, no marker
+packets, no measurable cost).  `cpu_baseline` is the plain-C restatement of the reference algorithm
+(oracle/offmark_oracle.c, bit-identical to the NumPy oracle and the reference-run golden vectors;
+OpenCV is not installed, so the reference itself cannot run) with one OpenMP thread per frame on the
+host cores this process may use.
 """
 import argparse
 import ctypes
@@ -38,7 +40,7 @@ PAYLOAD = np.array([0, 1, 1, 0, 0, 1, 0, 1])
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=300, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=1080)
@@ -56,7 +58,7 @@ def parse():
                     help="rehearsal only: every rank uses cuda:0 (a one-GPU box cannot run RCCL across ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket kernels with HIP events (roofline becomes null)")
+                    help="do not attach HIP events to the kernel launches (roofline becomes null)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -226,7 +228,8 @@ def main():
         torch.cuda.synchronize()
     if a.warmup:
         run(a.warmup)
-    launches_per_step = 5 * ((n + chunk - 1) // chunk)      # upper bound (4 with the fused verify kernel)
+    n_chunks = (n + chunk - 1) // chunk
+    launches_per_step = 5 * n_chunks                        # upper bound (3 with the fused verify kernel)
     use_events = not a.no_kernel_events
     KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd")
     DOMINANT = "mark_fused" if a.codec == "dct" else "svd"
@@ -238,8 +241,9 @@ def main():
         lib.ofmk_timing_disable()
         return {k: dict(ms_total=ms[i], launches=cnt[i]) for i, k in enumerate(KINDS)}
 
-    if use_events:
-        _hip.check(lib.ofmk_timing_enable(launches_per_step * a.steps + 16, 1 << KINDS.index(DOMINANT)))
+    timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
+    if use_events:                                          # every kernel of the timed steps carries its own event pair
+        _hip.check(lib.ofmk_timing_enable(launches_per_step * timed_steps + 16, 0x1F))
     fence()
     host_s.update(enqueue=0.0, vote=0.0)
     t0 = time.perf_counter()
@@ -254,15 +258,9 @@ def main():
 
     kern = None
     if use_events:
-        timed = collect()                      # dominant kernel, bracketed inside the timed region
-        extra_steps = min(a.steps, 5)          # everything else: separate instrumented pass
-        _hip.check(lib.ofmk_timing_enable(launches_per_step * extra_steps + 16, 0x1F))
-        run(extra_steps)
-        torch.cuda.synchronize()
-        kern = collect()
+        kern = collect()                       # per-launch durations from the timed region itself
         for v in kern.values():
-            v["steps"] = extra_steps
-        kern[DOMINANT] = dict(timed[DOMINANT], steps=a.steps, in_timed_region=True)
+            v["in_timed_region"] = True
 
     # correctness of what was timed: every frame's payload, every segment's vote
     payload_ok = bool((mine.cpu().numpy() == PAYLOAD[None]).all())
@@ -304,11 +302,11 @@ def main():
             if not v["launches"]:
                 continue
             avg_ms = v["ms_total"] / v["launches"]
-            d = dict(avg_launch_ms=round(avg_ms, 5), launches=v["launches"], ms_per_step=round(v["ms_total"] / v["steps"], 4),
+            passes = 2 if (k == "analyze" and not kern["mark_fused"]["launches"]) else 1
+            d = dict(avg_launch_ms=round(avg_ms, 5), launches=v["launches"], ms_per_step=round(avg_ms * n_chunks * passes, 4),
                      timed_region=bool(v.get("in_timed_region", False)))
             if k in alg:
-                passes = 2 if (k == "analyze" and not kern["mark_fused"]["launches"]) else 1
-                frames_per_launch = n * v["steps"] * passes / v["launches"]
+                frames_per_launch = n / n_chunks
                 d["algorithmic_bytes_per_launch"] = int(frames_per_launch * alg[k])
                 d["achieved_GBps"] = round(frames_per_launch * alg[k] / (avg_ms * 1e-3) / 1e9, 1)
             per[k] = d

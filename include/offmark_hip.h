@@ -147,8 +147,9 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
 int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream);
 
 /* Per-launch HIP-event timing for bench.py.  enable() pre-creates 2*max_launches events; while
- * enabled every launch of a kernel kind selected in kind_mask (bit k = kind k, 0 = all) is
- * bracketed by hipEventRecord on the launch stream; collect()
+ * enabled every launch of a kernel kind selected in kind_mask (bit k = kind k, 0 = all) carries an
+ * event pair as the dispatch's own start/stop events (hipExtLaunchKernelGGL) on the launch stream, so no
+ * marker packets separate consecutive kernels; collect()
  * waits for the recorded events, returns the summed milliseconds and launch counts per kernel
  * kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze, 4 DwtDctSvd) and rewinds the pool.  Not for use under graph capture. */
 int ofmk_timing_enable(int max_launches, unsigned kind_mask);
