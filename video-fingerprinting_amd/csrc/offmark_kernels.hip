@@ -160,18 +160,22 @@ bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block 
     return W % 8 == 0 && (uintptr_t)p % need == 0;
 }
 
-int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, hipStream_t s) {
-    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)n * kSlots * 8, s));
+// zero_counts (optional): [n][L] position sums of these frames, cleared by the kernel for a finalize that follows
+int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, hipStream_t s,
+                   int32_t *zero_counts = nullptr, int L = 0) {
+    // one fill for both accumulator arrays (they are adjacent): ysum for this pass, ysum2 for a fused mark+verify
+    // kernel that may follow -- one dispatch less per step than zeroing ysum2 in front of the mark kernel
+    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws);
     const dim3 grid = block_grid(g, n);
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
     ScopedTiming timing(KIND_ANALYZE, s);
     if (src == SRC_RGB8) {
-        if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
-        else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
+        if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
+        else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
     } else {
-        if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_YUV32F, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
-        else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_YUV32F, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum);
+        if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_YUV32F, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
+        else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_YUV32F, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
     }
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
@@ -189,8 +193,8 @@ int launch_finalize(FinArgs a, int n, hipStream_t s) {
 // Needs the input frames' records in ws.rec / ws.ysum (launch_analyze).  fused = true also leaves the
 // MARKED frames' records in ws.rec and their mean accumulators in ws.ysum2.
 int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
-                     double alpha, const Workspace &ws, bool fused, hipStream_t s) {
-    if (fused) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
+                     double alpha, const Workspace &ws, bool fused, hipStream_t s, bool ysum2_is_zero = false) {
+    if (fused && !ysum2_is_zero) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws);
     const dim3 grid = block_grid(g, n);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
@@ -286,17 +290,18 @@ int finalize_detect(int f0, int cf, int H, int W, int L, double alpha, int32_t *
 // analyze + mark for frames [f0, f0+cf); verify = also leave the marked frames' records in the
 // workspace (fused kernel), ready for finalize_detect(after_fused_mark = true)
 int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W, const uint8_t *wm,
-                const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, hipStream_t s) {
+                const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, hipStream_t s,
+                int32_t *zero_counts = nullptr, int L = 0) {
     const size_t fs = (size_t)H * W * 3;
     const size_t esz = src == SRC_RGB8 ? 1 : 4;
     const char *pin = static_cast<const char *>(in) + (size_t)f0 * fs * esz;
     char *pout = static_cast<char *>(out) + (size_t)f0 * fs * esz;
-    int rc = launch_analyze(pin, src, cf, H, W, ws, s);
+    int rc = launch_analyze(pin, src, cf, H, W, ws, s, zero_counts ? zero_counts + (size_t)f0 * L : nullptr, L);
     if (rc) return rc;
     const int32_t *rows = wm_row ? wm_row + f0 : nullptr;
     if (src == SRC_RGB8)
         return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, wm,
-                                rows, alpha, ws, verify, s);
+                                rows, alpha, ws, verify, s, /*ysum2_is_zero=*/true);   // by launch_analyze just above
     // float32 YUV plugin path: separate scalar stage, then the rank-1 update of channel 1
     FinArgs a = fin_base(ws, H, W, alpha);
     a.wm = wm;
@@ -314,7 +319,7 @@ int detect_chunk(const void *in, int src, int f0, int cf, int H, int W, int L, d
     const size_t fs = (size_t)H * W * 3;
     const size_t esz = src == SRC_RGB8 ? 1 : 4;
     const char *pin = static_cast<const char *>(in) + (size_t)f0 * fs * esz;
-    int rc = launch_analyze(pin, src, cf, H, W, ws, s);
+    int rc = launch_analyze(pin, src, cf, H, W, ws, s, counts ? counts + (size_t)f0 * L : nullptr, L);
     if (rc) return rc;
     return finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, false, s);
 }
@@ -417,8 +422,7 @@ int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
-    for (int f0 = 0; f0 < n; f0 += ws.frames) {
+    for (int f0 = 0; f0 < n; f0 += ws.frames) {      // counts are cleared by each chunk's analyze kernel
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         if ((rc = detect_chunk(in, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
     }
@@ -459,17 +463,18 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
+    const bool onepass = g_onepass && (((H / 8) * (W / 8) + kThreads - 1) / kThreads) <= 512;
+    if (counts && onepass) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));   // else: analyze clears them
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         // one-pass needs every tile of a frame in flight at once: 2 workgroups per CU are always resident
         // (150 VGPRs -> 3), so frames of up to 512 tiles (131 072 blocks, e.g. 4K) qualify
-        if (g_onepass && (((H / 8) * (W / 8) + kThreads - 1) / kThreads) <= 512) {
+        if (onepass) {
             const size_t fo = (size_t)f0 * H * W * 3;
             if ((rc = launch_onepass_rgb8(in + fo, out + fo, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, s))) return rc;
             if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
         } else if (g_fuse_verify) {
-            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, s))) return rc;
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, s, counts, L))) return rc;
             if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
         } else {
             if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
@@ -500,7 +505,6 @@ int ofmk_decode_yuv32f(const float *yuv, int n, int H, int W, int L, double alph
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         if ((rc = detect_chunk(yuv, SRC_YUV32F, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
