@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--alpha", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = alternate steps between two HIP streams (own workspace and output buffer each)")
+    ap.add_argument("--separate-detect", action="store_true",
+                    help="embed, then detect the written frames with the stand-alone detect kernels (analyze runs twice, "
+                         "12 B/px of traffic) instead of the fused mark+verify kernel; same results bit for bit")
     ap.add_argument("--onepass", type=int, default=-1, metavar="GRID",
                     help="DCT codec: use the persistent one-pass embed+verify kernel with GRID workgroups (0 = its default)")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
@@ -135,6 +138,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _hip.load()
+    if a.separate_detect:
+        lib.ofmk_set_fused_verify(0)
     if a.onepass >= 0:
         lib.ofmk_set_fused_verify(3)
         lib.ofmk_set_onepass_grid(a.onepass)
@@ -232,7 +237,7 @@ def main():
     launches_per_step = 5 * n_chunks                        # upper bound (3 with the fused verify kernel)
     use_events = not a.no_kernel_events
     KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd")
-    DOMINANT = "mark_fused" if a.codec == "dct" else "svd"
+    DOMINANT = ("mark" if a.separate_detect else "mark_fused") if a.codec == "dct" else "svd"
 
     def collect():
         ms = (ctypes.c_double * 5)()
@@ -344,7 +349,10 @@ def main():
                                f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} embed+detect+vote "
                                f"(BASELINE.json configs[{2 if H >= 2160 else 1}])", "codec": a.codec,
                    "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
-                   "chunk_frames": chunk, "sharding": f"frames, {world} rank(s), one RCCL all-gather of payloads"},
+                   "chunk_frames": chunk,
+                   "detect": ("separate kernels" if a.separate_detect else "one-pass kernel" if a.onepass >= 0
+                              else "fused into the mark kernel") if a.codec == "dct" else "fused into the embed kernel",
+                   "sharding": f"frames, {world} rank(s), one RCCL all-gather of payloads"},
         "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,
         "roofline": roof,
         "path": {"algorithmic_GBps": round(path_gbps, 1), "bytes_per_frame": 9 * H * W,
