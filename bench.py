@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--alpha", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = alternate steps between two HIP streams (own workspace and output buffer each)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with one rank: still create the process group and issue every collective of the N>1 path "
+                         "(1-rank RCCL all-gather on the side stream, barriers, MAX all-reduce) -- a dry run of that code")
     ap.add_argument("--separate-detect", action="store_true",
                     help="embed, then detect the written frames with the stand-alone detect kernels (analyze runs twice, "
                          "12 B/px of traffic) instead of the fused mark+verify kernel; same results bit for bit")
@@ -131,7 +134,8 @@ def main():
 
     if a.single_device:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world = init_from_env(a.backend)
+    rank, world = init_from_env(a.backend, force=a.rehearse_collectives)
+    grouped = world > 1 or a.rehearse_collectives          # a process group exists: run the collectives
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -167,6 +171,12 @@ def main():
 
     host_s = {"enqueue": 0.0, "vote": 0.0}     # host-side seconds spent issuing work / voting (not waiting)
 
+    def barrier():
+        if a.backend == "nccl":
+            dist.barrier(device_ids=[local])
+        else:
+            dist.barrier()
+
     def enqueue(k):
         """GPU half of step k: embed, detect the marked frames, per-frame payloads; then, on a side stream,
         the all-gather of the payloads and their download into pinned memory."""
@@ -183,10 +193,10 @@ def main():
         with torch.cuda.stream(side):
             side.wait_event(handoff[k & 1])
             mine.record_stream(side)
-            if a.backend == "gloo" and world > 1:                        # rehearsal: gloo gathers host tensors
-                everyone = gather_payloads(mine.cpu(), equal_shards=True)
+            if a.backend == "gloo" and grouped:                        # rehearsal: gloo gathers host tensors
+                everyone = gather_payloads(mine.cpu(), equal_shards=True, force=grouped)
             else:
-                everyone = gather_payloads(mine, equal_shards=True)      # RCCL all-gather (N > 1)
+                everyone = gather_payloads(mine, equal_shards=True, force=grouped)      # RCCL all-gather (N > 1)
             host[k & 1].copy_(everyone, non_blocking=True)
             ready[k & 1].record()
         host_s["enqueue"] += time.perf_counter() - t_in
@@ -211,8 +221,8 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if grouped:
+            barrier()
         torch.cuda.synchronize()
 
     # one-time setup, not a workload step: allocate the scratch for the chunk size in use and let the runtime load
@@ -227,9 +237,9 @@ def main():
                 _, c1, _ = lane["eng"].svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=lane["out"])
             p1 = lane["eng"].payloads(c1, N, perm_dev)
     torch.cuda.synchronize()
-    if world > 1:                                   # first collective on the side stream: RCCL sets its channels up here
+    if grouped:                                     # first collective on the side stream: RCCL sets its channels up here
         with torch.cuda.stream(side):
-            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=True)
+            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=True, force=grouped)
         torch.cuda.synchronize()
     if a.warmup:
         run(a.warmup)
@@ -256,7 +266,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in host_s.items()}
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -274,7 +284,7 @@ def main():
 
     if rank != 0:
         if world > 1:
-            dist.barrier()
+            barrier()
             dist.destroy_process_group()
         return
 
@@ -364,8 +374,8 @@ def main():
     }
     line.update(extra)
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if grouped:
+        barrier()
         dist.destroy_process_group()
 
 

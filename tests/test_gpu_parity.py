@@ -764,3 +764,25 @@ def test_random_shapes_contents_and_strengths(eng):
         c3, b3 = eng.detect(cuda(got), L, alpha=alpha, want_bits=True)
         assert np.array_equal(c3.cpu().numpy(), counts.cpu().numpy())
         assert np.array_equal(b3.cpu().numpy(), bits.cpu().numpy())
+
+
+def test_bench_dry_run_of_the_collective_path():
+    """bench.py with a one-rank RCCL group: the process-group set-up, the side-stream all-gather, the barriers and
+    the MAX all-reduce of the N>1 path all execute (on one GPU), and the line keeps its contract fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-collectives", "--frames", "8",
+                        "--height", "240", "--width", "320", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line
+    assert line["payload_bit_exact"] and line["n_gpus"] == 1 and line["steps"] == 3
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0

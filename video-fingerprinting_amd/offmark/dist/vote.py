@@ -21,14 +21,18 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def init_from_env(backend: str | None = None):
+def init_from_env(backend: str | None = None, force: bool = False):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
-    Returns (rank, world).  With WORLD_SIZE unset or 1 no group is created."""
+    Returns (rank, world).  With WORLD_SIZE unset or 1 no group is created unless ``force`` (a one-rank
+    group on 127.0.0.1, for dry runs of the collective path)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -52,15 +56,15 @@ def payloads_from_counts(counts, n_bits: int, perm):
     return (payload > thr).to(torch.uint8)
 
 
-def gather_payloads(local, equal_shards: bool = False):
+def gather_payloads(local, equal_shards: bool = False, force: bool = False):
     """all-gather per-frame payloads [n_local, L] uint8 -> [n_total, L] in rank order.
     ``equal_shards=True`` promises every rank holds the same number of frames: one collective, no size
     exchange and no host synchronisation (the benchmark's steady state).  Otherwise ragged shards are
     handled with a size exchange and padding."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+        return local            # ``force``: issue the collective even in a one-rank group (dry run)
     world = dist.get_world_size()
     if equal_shards:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
