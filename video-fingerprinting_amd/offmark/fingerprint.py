@@ -8,6 +8,9 @@ read by its detector and vice versa:
   * leak pattern -> one copy per segment            -- tests/generate_leak.py:59-108 (the selection rule)
   * view number -> base-C digit string              -- api/main.py:220-230
   * per-segment detection -> copy sequence          -- tests/detect_watermarks.py:345-364 (no-mapping branch)
+  * segment file name -> segment number             -- tests/detect_watermarks.py:50-80
+Pinned by tests/golden/fingerprint_layer.json: inputs/outputs of the reference's own functions
+(tools/make_fingerprint_golden.py).
 """
 from __future__ import annotations
 
@@ -51,6 +54,19 @@ def view_to_copies(view_number: int, num_copies: int, num_segments: int) -> list
         digits.append(0)
     digits.reverse()
     return digits
+
+
+def segment_number_from_filename(filename: str):
+    """Segment number of a segment file (tests/detect_watermarks.py:50-80): the first '_'-separated part of the
+    basename that is all digits, else the first run of digits anywhere in the basename, else None."""
+    import os
+    import re
+    base = os.path.basename(filename)
+    for part in base.split("_"):
+        if part.isdigit():
+            return int(part)
+    m = re.search(r"(\d+)", base)
+    return int(m.group(1)) if m else None
 
 
 def identify_copies(segment_votes: dict, segment_numbers=None) -> list[int | None]:
