@@ -58,3 +58,19 @@ def test_segment_number_from_filename(g):
     from offmark import fingerprint as fp
     for name, expected in g["segment_number_from_filename"]:   # tests/detect_watermarks.py:50-80
         assert fp.segment_number_from_filename(name) == expected, name
+
+
+def test_cross_frame_vote_against_the_reference_collector(g):
+    """a10: PatternCollectorExtractor.start() of the reference (segment_mark_detect_hls.py:119-155,
+    detect_watermarks.py:101-137) run on prescribed per-frame patterns, ties and the empty case included."""
+    from offmark.dist.vote import vote, vote_segments
+    for _script, name, patterns, winner, freq in g["cross_frame_vote"]:
+        rows = np.asarray(patterns, dtype=np.int64).reshape(len(patterns), -1) if patterns else np.zeros((0, 8), np.int64)
+        pattern, f = vote(rows)
+        if winner is None:
+            assert pattern is None and f is None, name
+            continue
+        assert pattern.tolist() == winner and f == freq, name
+        # the all-segments-at-once form agrees, whatever else shares the batch
+        both = vote_segments(np.concatenate([rows, rows[::-1]]), np.repeat([3, 9], len(rows)))
+        assert both[3][0].tolist() == winner and both[3][1] == freq, name

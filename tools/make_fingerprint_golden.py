@@ -37,6 +37,72 @@ def functions_of(relpath, names, extra=None):
     return ns
 
 
+def classes_of(relpath, names, extra=None):
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert {n.name for n in picked} == set(names), (relpath, names)
+    ns = {"np": np, "logger": logging.getLogger("reference")}
+    ns.update(extra or {})
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+class _Frames:            # frame_reader stand-in: hands out frame numbers as 1x1x3 "frames", then None
+    def __init__(self, n):
+        self.n, self.i = n, 0
+
+    def read(self):
+        if self.i >= self.n:
+            return None
+        self.i += 1
+        return np.full((1, 1, 3), self.i - 1, dtype=np.uint8)
+
+    def close(self):
+        pass
+
+
+class _Cv2:               # the vote does not depend on the colour transform: pass frames through
+    COLOR_BGR2YUV = 0
+
+    @staticmethod
+    def cvtColor(a, code):
+        return a
+
+
+def reference_votes():
+    """Cross-frame vote (a10): the reference's PatternCollectorExtractor.start() over prescribed per-frame patterns."""
+    from collections import Counter
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 2, (4, 8))
+    cases = {
+        "unanimous": [base[0]] * 7,
+        "majority": [base[0], base[1], base[0], base[2], base[0]],
+        "tie_first_seen_wins": [base[1], base[0], base[0], base[1]],
+        "tie_three_way": [base[2], base[1], base[0]],
+        "late_majority": [base[3], base[2], base[2], base[3], base[2]],
+        "single": [base[1]],
+        "empty": [],
+        "random_40": [base[i] for i in rng.integers(0, 4, 40)],
+        "random_41": [base[i] for i in rng.integers(0, 3, 41)],
+    }
+    rows = []
+    for script in ("tests/segment_mark_detect_hls.py", "tests/detect_watermarks.py"):
+        ns = classes_of(script, ["PatternCollectorExtractor"], {"cv2": _Cv2, "Counter": Counter})
+        for name, patterns in cases.items():
+            class _Decoder:
+                def decode(self, yuv):
+                    return int(yuv[0, 0, 0])
+
+            class _Degenerator:
+                def degenerate(self, k):
+                    return np.asarray(patterns[k])
+            pattern, freq = ns["PatternCollectorExtractor"](_Frames(len(patterns)), _Decoder(), _Degenerator()).start()
+            rows.append([script, name, [np.asarray(p).tolist() for p in patterns],
+                         None if pattern is None else np.asarray(pattern).tolist(), freq])
+    return rows
+
+
 def main():
     out = {"_made_by": "tools/make_fingerprint_golden.py from the reference's own function definitions"}
 
@@ -115,6 +181,8 @@ def main():
             short = str(exc)
         out["select_copies"] = {"segments": segs, "copies": ncopies, "cases": sel, "too_short_message": short,
                                 "files_written": sorted(os.path.basename(p) for p in paths)}
+
+    out["cross_frame_vote"] = reference_votes()
 
     dst = os.path.join(ROOT, "tests", "golden", "fingerprint_layer.json")
     with open(dst, "w") as f:
