@@ -4,27 +4,40 @@
 One "step" = one pass of the hot path over one batch of synthetic frames resident in HBM:
 embed every frame, detect the produced frames, recover each frame's payload, all-gather the
 payloads over the ranks (RCCL; a no-op on one GPU) and take the cross-frame vote.
-Workload at N=1: BASELINE.json configs[1] -- 300 synthetic 1080p frames, payload
-[0,1,1,0,0,1,0,1], Shuffler(key=0), alpha=20.  With N ranks every rank holds its own 300 frames
-(weak scaling, frames shard with no data-path collective).
+
+  --config 2 (default)  BASELINE.json configs[1]: 300 synthetic 1080p frames per GPU, payload
+                        [0,1,1,0,0,1,0,1], Shuffler(key=0), alpha=20.  Weak scaling: every rank holds its
+                        own 300 frames (frames shard with no data-path collective).
+  --config 3            configs[2]: 1000 synthetic 4K frames per GPU, processed in internal chunks.
+  --config 4            configs[3]: 8 segments x 48 frames of 1080p, segment s carries format(s % 256, '08b')
+                        (tests/segment_mark_detect_hls.py:42-55), segments sharded over the ranks (strong
+                        scaling), per-segment Counter vote on every rank.
+  --config 5            configs[4]: leak identification (tests/generate_leak.py:59-108 +
+                        tests/detect_watermarks.py:321-364): 8 segments x 3 copies are marked in set-up
+                        (payload = segment(4b)||copy(4b)), a leak takes one copy per segment plus the
+                        build-defined re-quantisation attack; the timed step is the batched DETECT of the
+                        leak's frames, the all-gather of the payloads and the vote -> copy sequence.
 
   python bench.py --gpus 1 --steps 100 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused mark+verify kernel:
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (config 2: the fused mark+verify kernel:
 it re-reads each frame, writes the marked frame and analyzes it).  Launch durations (`kernels`) come
 from HIP event pairs the library attaches to every kernel dispatch of the timed steps
 (hipExtLaunchKernelGGL start/stop events on the launch stream: the dispatch's own timestamps, no marker
-packets, no measurable cost).  `cpu_baseline` is the plain-C restatement of the reference algorithm
-(oracle/offmark_oracle.c, bit-identical to the NumPy oracle and the reference-run golden vectors;
-OpenCV is not installed, so the reference itself cannot run) with one OpenMP thread per frame on the
-host cores this process may use.
+packets, no measurable cost).  `roofline.traffic` (PMC-measured HBM bytes per launch) is taken from
+profiles/ only when that profile was made from exactly the kernel sources that are running (hash stamp),
+else null.  `cpu_baseline` is the plain-C restatement of the reference algorithm (oracle/offmark_oracle.c,
+bit-identical to the NumPy oracle and the golden vectors; kind "port": OpenCV is not installed, so the
+reference itself cannot run, and OpenCV's own float rounding is parity-unpinned) with one OpenMP thread per
+frame on the host cores this process may use; `cpu_baseline.variants` adds BASELINE.md's A / B1 / B2 forms.
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -42,9 +55,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=300, help="frames per GPU per step")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload (see module text)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (configs 4/5: per segment); 0 = the config's own")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0, help="frames per internal chunk (0 = engine default)")
     ap.add_argument("--alpha", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
@@ -55,8 +69,6 @@ def parse():
     ap.add_argument("--separate-detect", action="store_true",
                     help="embed, then detect the written frames with the stand-alone detect kernels (analyze runs twice, "
                          "12 B/px of traffic) instead of the fused mark+verify kernel; same results bit for bit")
-    ap.add_argument("--onepass", type=int, default=-1, metavar="GRID",
-                    help="DCT codec: use the persistent one-pass embed+verify kernel with GRID workgroups (0 = its default)")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
                     help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
@@ -65,8 +77,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not attach HIP events to the kernel launches (roofline becomes null)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the separate-detect side measurement")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of the CPU baseline's main (C, all cores) sample")
     return ap.parse_args()
+
+
+def source_sha16():
+    """Hash of everything the library is compiled from: stamps profiles so a stale one is never quoted."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "video-fingerprinting_amd", "csrc")
+    for path in sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, "include", "offmark_hip.h")]:
+        h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def usable_cores():
@@ -90,14 +112,16 @@ def usable_cores():
 
 def cpu_baseline(frames_u8, wm, alpha, budget_s):
     """The oracle on the host cores, embed+detect on a bounded sample of the same workload.
-    Primary figure: the C restatement (oracle/offmark_oracle.c, bit-identical to the NumPy oracle), one OpenMP
-    thread per frame on every core this process may use.  The vectorised NumPy oracle on one core is timed on a
-    few frames as well and quoted in `sample` (the reference itself is single-threaded Python + OpenCV)."""
+    value: the C restatement (oracle/offmark_oracle.c, bit-identical to the NumPy oracle), one OpenMP thread per
+    frame on every core this process may use.  variants: BASELINE.md section 3's forms of the NumPy oracle --
+    A reference-shaped per-block Python loop on one core, B1 all-blocks-at-once NumPy on one core, B2 = B1 in one
+    worker process per core (oracle/cpu_baseline_worker.py; separate processes that never touch the GPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     import offmark_oracle as orc
     threads = usable_cores()
     n = len(frames_u8)
+    H, W = frames_u8.shape[1:3]
     done, ok, t0 = 0, True, time.perf_counter()
     while True:
         marked, used = c_oracle.mark_frames(frames_u8, wm, alpha=alpha, legacy=True, threads=threads)
@@ -108,17 +132,47 @@ def cpu_baseline(frames_u8, wm, alpha, budget_s):
         if el + el * n / done > budget_s:
             break
     el = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    enc = orc.DctEncoderOracle(alpha=alpha)
-    enc.read_wm(wm)
-    k = 3
-    for i in range(k):
-        orc.check_frame(orc.mark_frame(frames_u8[i], enc), orc.DctDecoderOracle(alpha=alpha))
-    numpy_fps = k / (time.perf_counter() - t1)
+    variants = {}
+    try:
+        # B1: vectorised NumPy, one core
+        enc = orc.DctEncoderOracle(alpha=alpha)
+        enc.read_wm(wm)
+        t1, k = time.perf_counter(), 3
+        for i in range(k):
+            orc.check_frame(orc.mark_frame(frames_u8[i], enc), orc.DctDecoderOracle(alpha=alpha))
+        variants["B1_numpy_vectorised"] = dict(value=round(k / (time.perf_counter() - t1), 2), unit="frames/s", cores=1, frames=k)
+        # A: reference-shaped per-block Python loop, one core, on a quarter-frame crop scaled by its block count
+        crop = np.ascontiguousarray(frames_u8[0][: H // 16 * 8, : W // 16 * 8])
+        ch, cw = crop.shape[:2]
+        encl = orc.DctEncoderOracle(alpha=alpha, form="loop")
+        encl.read_wm(orc.shuffle_generate(PAYLOAD, (1, ch * cw // 64), 0))
+        t2 = time.perf_counter()
+        orc.check_frame(orc.mark_frame(crop, encl), orc.DctDecoderOracle(alpha=alpha, form="loop"))
+        ta = (time.perf_counter() - t2) * ((H // 8) * (W // 8)) / ((ch // 8) * (cw // 8))
+        variants["A_reference_shaped_loop"] = dict(value=round(1.0 / ta, 3), unit="frames/s", cores=1,
+                                                   frames=round((ch * cw) / (H * W), 3),
+                                                   note=f"timed on a {cw}x{ch} crop, scaled by the block count")
+    except Exception as exc:
+        variants["error_A_B1"] = repr(exc)
+    # B2: B1 fanned out, one worker process per core
+    try:
+        per = 2
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline_worker.py"), str(H), str(W),
+                                   str(per), str(3000 + i), str(alpha)], stdout=subprocess.PIPE, text=True, env=env)
+                 for i in range(threads)]
+        spans = [json.loads(p.communicate(timeout=300)[0].strip().splitlines()[-1]) for p in procs]
+        wall = max(s["t1"] for s in spans) - min(s["t0"] for s in spans)
+        variants["B2_numpy_vectorised_all_cores"] = dict(value=round(threads * per / wall, 2), unit="frames/s", cores=threads,
+                                                         frames=threads * per, payload_ok=all(s["ok"] for s in spans))
+    except Exception as exc:                                   # report, never lose the line
+        variants["B2_numpy_vectorised_all_cores"] = dict(value=None, error=repr(exc))
     return dict(value=done / el, unit="frames/s", cores=used, kind="port",
-                sample=f"{done} frame passes ({n} distinct {frames_u8.shape[2]}x{frames_u8.shape[1]} frames of the workload), "
-                       f"embed+detect, C restatement of the reference algorithm with OpenMP over frames on {used} threads, "
-                       f"{el:.1f} s; payload recovered: {ok}; vectorised NumPy oracle on 1 core: {numpy_fps:.1f} frames/s")
+                sample=f"{done} frame passes ({n} distinct {W}x{H} frames of the workload), embed+detect, C restatement of the "
+                       f"reference algorithm with OpenMP over frames on {used} threads, {el:.1f} s; payload recovered: {ok}. "
+                       "The reference itself needs OpenCV (absent): DCT/colour primitives are restated, OpenCV's float "
+                       "rounding is parity-unpinned",
+                variants=variants)
 
 
 def main():
@@ -126,8 +180,9 @@ def main():
     import torch
     import torch.distributed as dist
     from offmark import _hip
+    from offmark import fingerprint as fp
     from offmark.degenerator.de_shuffler import DeShuffler
-    from offmark.dist.vote import gather_payloads, init_from_env, vote_segments
+    from offmark.dist.vote import gather_payloads, init_from_env, shard_range, vote_segments
     from offmark.engine import DctEngine, default_chunk_frames
     from offmark.generator.shuffler import Shuffler
     from offmark.synthetic import synthetic_frames
@@ -142,28 +197,75 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _hip.load()
-    if a.separate_detect:
-        lib.ofmk_set_fused_verify(0)
-    if a.onepass >= 0:
-        lib.ofmk_set_fused_verify(3)
-        lib.ofmk_set_onepass_grid(a.onepass)
+    flags = _hip.F_SEPARATE_DETECT if a.separate_detect else 0
 
-    n, H, W = a.frames, a.height, a.width
+    # ---- workload ------------------------------------------------------------------------------------
+    cfg = a.config
+    H = a.height or (2160 if cfg == 3 else 1080)
+    W = a.width or (3840 if cfg == 3 else 1920)
     N = H * W // 64
-    frames = synthetic_frames(n, H, W, seed=2000 + rank, device=dev)
-    out = torch.empty_like(frames)
-    wm = Shuffler(key=0).generate_wm(PAYLOAD, (1, N))
-    wm_dev = torch.from_numpy(wm.astype(np.uint8)).to(dev)
     deg = DeShuffler(key=0).set_shape(PAYLOAD.shape)
+    S, F, C = 8, 48, 3                                       # configs 4/5: segments, frames per segment, copies
+    chosen = None
+    if cfg in (2, 3):
+        scaling, equal = "weak", True
+        n = a.frames or (1000 if cfg == 3 else 300)
+        frames = synthetic_frames(n, H, W, seed=2000 + rank, device=dev)
+        wm_table = Shuffler(key=0).generate_wm(PAYLOAD, (1, N)).astype(np.uint8)
+        rows_local = None
+        seg_global = np.repeat(np.arange(world), n)          # one "segment" per rank
+        first = rank * n
+        expected = {r: PAYLOAD for r in range(world)}
+        total_frames = world * n
+        mode = "embed_detect"
+    else:
+        scaling = "strong"                                   # the 8-segment job is split over the ranks
+        if a.frames:
+            F = a.frames
+        s0, s1 = shard_range(S, rank, world)
+        n, first = (s1 - s0) * F, s0 * F
+        equal = S % world == 0
+        seg_global = np.repeat(np.arange(S), F)
+        total_frames = S * F
+        src = synthetic_frames(max(n, 1), H, W, seed=4000 + rank, device=dev)[:n]
+        if cfg == 4:
+            # segment s carries format(s % 256, '08b'); numbering starts at 1 because segment 0's all-zero payload
+            # cannot be decoded by the reference's mid-range threshold (de_shuffler.py:20-21)
+            payloads = np.stack([fp.payload_for_segment(s + 1) for s in range(S)])
+            wm_table = np.stack([Shuffler(key=0).generate_wm(p, (1, N))[0] for p in payloads]).astype(np.uint8)
+            rows_local = np.repeat(np.arange(s0, s1), F).astype(np.int32)
+            expected = {s: payloads[s] for s in range(S)}
+            frames = src
+            mode = "embed_detect"
+        else:
+            table = np.stack([Shuffler(key=0).generate_wm(fp.payload_for_segment(s + 1, c), (1, N))[0]
+                              for s in range(S) for c in range(C)]).astype(np.uint8)
+            chosen = fp.select_copies("01201201", S, C)
+            rows = np.array([(s * C + chosen[s]) for s in range(s0, s1) for _ in range(F)], dtype=np.int32)
+            setup = DctEngine(device=dev)
+            leak = setup.embed(src, table, alpha=a.alpha, wm_row=rows) if n else src
+            g = torch.Generator(device=dev).manual_seed(7 + rank)    # build-defined attack (i): N(0, 2) + round/clip
+            frames = (leak.float() + 2.0 * torch.randn(leak.shape, device=dev, generator=g)).round().clamp(0, 255).to(torch.uint8)
+            del leak, setup
+            wm_table, rows_local = None, None
+            expected = {s: fp.payload_for_segment(s + 1, chosen[s]) for s in range(S)}
+            mode = "detect"
+    out = torch.empty_like(frames) if mode == "embed_detect" else None
+    wm_dev = torch.from_numpy(wm_table).to(dev) if wm_table is not None else None
+    rows_dev = torch.from_numpy(rows_local).to(dev) if rows_local is not None else None
     chunk = a.chunk or default_chunk_frames(H, W)
-    eng = DctEngine(device=dev, chunk_frames=chunk)
-    lanes = [dict(eng=eng, out=out, stream=torch.cuda.current_stream())]
+    n_chunks = max(1, (n + chunk - 1) // chunk)
+    timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
+    timing = None if a.no_kernel_events else _hip.Timing(6 * n_chunks * timed_steps + 16)
+    opts_plain = _hip.Opts(flags, 0, None)
+    opts_timed = timing.opts(flags) if timing else opts_plain
+    lanes = [dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain), out=out, stream=torch.cuda.current_stream())]
     if a.streams == 2:
-        lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk), out=torch.empty_like(frames), stream=torch.cuda.Stream()))
-    seg_ids = np.repeat(np.arange(world), n)             # one segment per rank
+        lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain),
+                          out=torch.empty_like(frames) if out is not None else None, stream=torch.cuda.Stream()))
 
     perm_dev = torch.as_tensor(deg.payload_idx, dtype=torch.int32).to(dev)
-    host = [torch.empty((world * n, PAYLOAD.size), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    host = [torch.empty((total_frames, PAYLOAD.size), dtype=torch.uint8).pin_memory() for _ in range(2)]
     ready = [torch.cuda.Event() for _ in range(2)]
 
     side = torch.cuda.Stream()                    # all-gather + download: off the compute stream, so a slow
@@ -177,26 +279,33 @@ def main():
         else:
             dist.barrier()
 
+    def hot_path(e, lane_out):
+        """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames."""
+        if n == 0:
+            return torch.empty((0, PAYLOAD.size), dtype=torch.uint8, device=dev)
+        if mode == "detect":
+            counts, _ = e.detect(frames, PAYLOAD.size, alpha=a.alpha)
+        elif a.codec == "dct":
+            _, counts, _ = e.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, wm_row=rows_dev, out=lane_out)
+        else:
+            _, counts, _ = e.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, wm_row=rows_dev, out=lane_out)
+        return e.payloads(counts, N, perm_dev)                             # [n, L] uint8, on device
+
     def enqueue(k):
-        """GPU half of step k: embed, detect the marked frames, per-frame payloads; then, on a side stream,
-        the all-gather of the payloads and their download into pinned memory."""
+        """GPU half of step k; then, on a side stream, the all-gather of the payloads and their download into
+        pinned memory."""
         t_in = time.perf_counter()
         lane = lanes[k % len(lanes)]
-        e = lane["eng"]
         with torch.cuda.stream(lane["stream"]):
-            if a.codec == "dct":
-                _, counts, _ = e.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=lane["out"])
-            else:
-                _, counts, _ = e.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=lane["out"])
-            mine = e.payloads(counts, N, perm_dev)                       # [n, L] uint8, on device
+            mine = hot_path(lane["eng"], lane["out"])
             handoff[k & 1].record()
         with torch.cuda.stream(side):
             side.wait_event(handoff[k & 1])
             mine.record_stream(side)
             if a.backend == "gloo" and grouped:                        # rehearsal: gloo gathers host tensors
-                everyone = gather_payloads(mine.cpu(), equal_shards=True, force=grouped)
+                everyone = gather_payloads(mine.cpu(), equal_shards=equal, force=grouped)
             else:
-                everyone = gather_payloads(mine, equal_shards=True, force=grouped)      # RCCL all-gather (N > 1)
+                everyone = gather_payloads(mine, equal_shards=equal, force=grouped)      # RCCL all-gather (N > 1)
             host[k & 1].copy_(everyone, non_blocking=True)
             ready[k & 1].record()
         host_s["enqueue"] += time.perf_counter() - t_in
@@ -207,16 +316,16 @@ def main():
         It runs while the GPU is already working on step k+1 (double-buffered)."""
         ready[k & 1].synchronize()
         t_in = time.perf_counter()
-        v = vote_segments(host[k & 1].numpy(), seg_ids)
+        v = vote_segments(host[k & 1].numpy(), seg_global)
         host_s["vote"] += time.perf_counter() - t_in
         return v
 
     def run(steps):
-        votes, mine = None, None
+        mine = None
         for k in range(steps):
             mine = enqueue(k)
             if k:
-                votes = finish(k - 1)
+                finish(k - 1)
         return finish(steps - 1), mine
 
     def fence():
@@ -225,62 +334,73 @@ def main():
             barrier()
         torch.cuda.synchronize()
 
+    def timed(steps):
+        fence()
+        host_s.update(enqueue=0.0, vote=0.0)
+        t0 = time.perf_counter()
+        votes, mine = run(steps)
+        fence()
+        el = time.perf_counter() - t0
+        if grouped:
+            t = torch.tensor([el], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, votes, mine
+
     # one-time setup, not a workload step: allocate the scratch for the chunk size in use and let the runtime load
     # the code objects (one full-size pass, so that profiles only ever see full-size launches); even --warmup 0 then
     # times steady-state steps
     for lane in lanes:
-        lane["eng"].workspace(H, W, lane["eng"]._chunk(n, H, W))
+        if n:
+            lane["eng"].workspace(H, W, lane["eng"]._chunk(n, H, W))
         with torch.cuda.stream(lane["stream"]):
-            if a.codec == "dct":
-                _, c1, _ = lane["eng"].embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, out=lane["out"])
-            else:
-                _, c1, _ = lane["eng"].svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, out=lane["out"])
-            p1 = lane["eng"].payloads(c1, N, perm_dev)
+            p1 = hot_path(lane["eng"], lane["out"])
     torch.cuda.synchronize()
     if grouped:                                     # first collective on the side stream: RCCL sets its channels up here
         with torch.cuda.stream(side):
-            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=True, force=grouped)
+            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=equal, force=grouped)
         torch.cuda.synchronize()
     if a.warmup:
         run(a.warmup)
-    n_chunks = (n + chunk - 1) // chunk
-    launches_per_step = 5 * n_chunks                        # upper bound (3 with the fused verify kernel)
-    use_events = not a.no_kernel_events
-    KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd")
-    DOMINANT = ("mark" if a.separate_detect else "mark_fused") if a.codec == "dct" else "svd"
+    DOMINANT = ("analyze" if mode == "detect" else "mark" if a.separate_detect else "mark_fused") if a.codec == "dct" else "svd"
 
-    def collect():
-        ms = (ctypes.c_double * 5)()
-        cnt = (ctypes.c_int * 5)()
-        _hip.check(lib.ofmk_timing_collect(ms, cnt))
-        lib.ofmk_timing_disable()
-        return {k: dict(ms_total=ms[i], launches=cnt[i]) for i, k in enumerate(KINDS)}
-
-    timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
-    if use_events:                                          # every kernel of the timed steps carries its own event pair
-        _hip.check(lib.ofmk_timing_enable(launches_per_step * timed_steps + 16, 0x1F))
-    fence()
-    host_s.update(enqueue=0.0, vote=0.0)
-    t0 = time.perf_counter()
-    votes, mine = run(a.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
+    for lane in lanes:
+        lane["eng"].opts = opts_timed                       # every kernel of the timed steps carries its own event pair
+    elapsed, votes, mine = timed(a.steps)
     host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in host_s.items()}
-    if grouped:
-        t = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    for lane in lanes:
+        lane["eng"].opts = opts_plain
     kern = None
-    if use_events:
-        kern = collect()                       # per-launch durations from the timed region itself
-        for v in kern.values():
-            v["in_timed_region"] = True
+    if timing:
+        kern = timing.collect()                # per-launch durations from the timed region itself
+        timing.close()
 
-    # correctness of what was timed: every frame's payload, every segment's vote
-    payload_ok = bool((mine.cpu().numpy() == PAYLOAD[None]).all())
-    votes_ok = all(v[0] is not None and np.array_equal(v[0], PAYLOAD) for v in votes.values())
-    ber = float((mine.cpu().numpy() != PAYLOAD[None]).mean())
+    # correctness of what was timed: every frame's payload, every segment's vote (and the leak's copy sequence)
+    want_mine = np.stack([expected[s] for s in seg_global[first:first + n]]) if n else np.zeros((0, PAYLOAD.size), np.int64)
+    got_mine = mine.cpu().numpy()
+    ber = float((got_mine != want_mine).mean()) if n else 0.0
+    votes_ok = len(votes) == len(expected) and all(v[0] is not None and np.array_equal(v[0], expected[s]) for s, v in votes.items())
+    payload_ok = bool((got_mine == want_mine).all())
+    if cfg == 5:     # under the noise attack single frames may misread; what must hold is the vote -> copy sequence
+        votes_ok = votes_ok and fp.identify_copies({s + 1: v for s, v in votes.items()}) == chosen
+        payload_ok = votes_ok
+
+    # second figure of the same line: SURVEY 8d config 2 read literally (embed, then the stand-alone detect)
+    extra = {}
+    if cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras:
+        sep = _hip.Opts(_hip.F_SEPARATE_DETECT, 0, None)
+        for lane in lanes:
+            lane["eng"].opts = sep
+        k2 = max(3, min(a.steps, 20))
+        run(1)
+        el2, v2, _ = timed(k2)
+        for lane in lanes:
+            lane["eng"].opts = opts_plain
+        extra["value_separate_detect"] = round(world * n * k2 / el2, 1)
+        extra["separate_detect"] = dict(steps=k2, ms_per_step=round(1e3 * el2 / k2, 4),
+                                        note="embed, then the stand-alone detect on the written frames (12 B/px real traffic); "
+                                             "bit-identical results",
+                                        votes_ok=all(np.array_equal(v[0], expected[s]) for s, v in v2.items()))
 
     if rank != 0:
         if world > 1:
@@ -288,23 +408,34 @@ def main():
             dist.destroy_process_group()
         return
 
-    # achievable HBM bandwidth of this device, same run: 16-byte streaming copy, read + write
-    nbytes = frames.numel() // 16 * 16
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # achievable HBM bandwidth of this device, same run: 16-byte streaming copy (read + write) and read-only stream
+    if frames.numel() >= (1 << 28) and out is not None:
+        probe_src, probe_dst = frames, out
+    else:
+        probe_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 256)
+        probe_dst = torch.empty_like(probe_src)
+    nbytes = probe_src.numel() // 16 * 16
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
     s = _hip.current_stream()
-    for _ in range(2):
-        _hip.check(lib.ofmk_hbm_copy(frames.data_ptr(), out.data_ptr(), nbytes, s))
-    e0.record()
-    for _ in range(5):
-        _hip.check(lib.ofmk_hbm_copy(frames.data_ptr(), out.data_ptr(), nbytes, s))
-    e1.record()
-    torch.cuda.synchronize()
-    copy_gbps = 5 * 2 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    fps = world * n * a.steps / elapsed
+    def probe(fn, moved):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            fn()
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 5 * moved / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    copy_gbps = probe(lambda: _hip.check(lib.ofmk_hbm_copy(probe_src.data_ptr(), probe_dst.data_ptr(), nbytes, s)), 2 * nbytes)
+    read_gbps = probe(lambda: _hip.check(lib.ofmk_hbm_read(probe_src.data_ptr(), nbytes, sink.data_ptr(), s)), nbytes)
+
+    fps = total_frames * a.steps / elapsed
     frame_bytes = 3 * H * W
     roof = None
-    extra = {}
+    sha = source_sha16()
     if kern:
         # algorithmic bytes per frame and kernel: analyze reads the frame (3 B/px);
         # mark reads it again and writes the marked frame (6 B/px); the fused mark+verify kernel
@@ -312,63 +443,79 @@ def main():
         alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes, "svd": 2 * frame_bytes}
         names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>",
                  "svd": "svd_rgb8_kernel<embed+verify>"}
+        ceiling = {"analyze": read_gbps, "mark": copy_gbps, "mark_fused": copy_gbps, "svd": copy_gbps}
         per = {}
         for k, v in kern.items():
             if not v["launches"]:
                 continue
             avg_ms = v["ms_total"] / v["launches"]
-            passes = 2 if (k == "analyze" and not kern["mark_fused"]["launches"]) else 1
-            d = dict(avg_launch_ms=round(avg_ms, 5), launches=v["launches"], ms_per_step=round(avg_ms * n_chunks * passes, 4),
-                     timed_region=bool(v.get("in_timed_region", False)))
+            d = dict(avg_launch_ms=round(avg_ms, 5), launches=v["launches"], ms_per_step=round(v["ms_total"] / a.steps, 4))
             if k in alg:
                 frames_per_launch = n / n_chunks
                 d["algorithmic_bytes_per_launch"] = int(frames_per_launch * alg[k])
                 d["achieved_GBps"] = round(frames_per_launch * alg[k] / (avg_ms * 1e-3) / 1e9, 1)
+                d["frac_of_peak"] = round(d["achieved_GBps"] / HBM_PEAK_GBPS, 4)
+                d["frac_of_measured_" + ("read" if k == "analyze" else "copy")] = round(d["achieved_GBps"] / ceiling[k], 4)
             per[k] = d
         extra["kernels"] = per
         extra["kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in per.values()), 4)
         dom = DOMINANT if DOMINANT in per else max((k for k in per if k in alg), key=lambda k: per[k]["ms_per_step"])
         achieved = per[dom]["achieved_GBps"]
-        traffic = None                          # PMC-measured HBM bytes per launch (separate rocprofv3 passes)
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if (tj["height"], tj["width"]) == (H, W) and dom in tj:
+        # PMC-measured HBM bytes per launch (separate rocprofv3 passes, tools/prof.sh): quoted only when that profile
+        # was taken from exactly these kernel sources and this frame size
+        traffic, traffic_src = None, None
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if tj.get("source_sha16") == sha and (tj["height"], tj["width"]) == (H, W) and dom in tj:
                 per_frame = (tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]) / tj["frames_per_dispatch"]
                 traffic = int(per_frame * per[dom]["algorithmic_bytes_per_launch"] / alg[dom])
+                traffic_src = f"profiles/{name} (source {sha})"
+                break
         roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=per[dom]["algorithmic_bytes_per_launch"],
                     avg_launch_ms=per[dom]["avg_launch_ms"], launches=per[dom]["launches"],
-                    frac_of_measured_copy=round(achieved / copy_gbps, 4))
+                    frac_of_measured_copy=round(achieved / copy_gbps, 4),
+                    frac_of_measured_read=round(achieved / read_gbps, 4))
 
     base = None
-    if world == 1 and not a.no_cpu_baseline and a.codec == "dct":
+    if world == 1 and not a.no_cpu_baseline and a.codec == "dct" and mode == "embed_detect":
         try:
-            base = cpu_baseline(frames[:96].cpu().numpy(), wm, a.alpha, a.cpu_seconds)
+            nb = 96 if H * W <= 1920 * 1080 else 24
+            wm_cpu = Shuffler(key=0).generate_wm(PAYLOAD, (1, N))
+            base = cpu_baseline(synthetic_frames(nb, H, W, seed=2000, device=dev).cpu().numpy(), wm_cpu, a.alpha, a.cpu_seconds)
         except Exception as exc:                       # e.g. no C compiler on the box: report, do not lose the GPU line
             base = dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"cpu baseline failed: {exc!r}")
 
-    path_gbps = fps * 9 * H * W / 1e9                                   # 9 B/px per embed+detect frame
+    # 9 B/px per embed+detect frame with the DCT codec; the DwtDctSvd codec has no frame-global
+    # dependency and no separate detect read: 6 B/px; detect only: 3 B/px
+    bpp = 3 if mode == "detect" else 9 if a.codec == "dct" else 6
+    path_gbps = fps * bpp * H * W / 1e9
+    what = {2: "configs[1]", 3: "configs[2]", 4: "configs[3]", 5: "configs[4]"}[cfg]
+    op = "embed+detect" if mode == "embed_detect" else "leak detect"
+    if cfg in (2, 3):
+        workload = f"synthetic {W}x{H} u8 RGB x{n} frames per GPU, "
+    else:
+        workload = (f"synthetic {W}x{H} u8 RGB, {S} segments x {F} frames sharded over {world} rank(s), "
+                    + ("own payload per segment, " if cfg == 4 else f"{C} copies per segment, leak 01201201 + N(0,2) noise, "))
     line = {
-        "metric": "1080p frames/sec embed+detect" if (H, W) == (1080, 1920) else f"{W}x{H} frames/sec embed+detect",
+        "metric": f"1080p frames/sec {op}" if (H, W) == (1080, 1920) else f"{W}x{H} frames/sec {op}",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic {W}x{H} u8 RGB x{n} frames per GPU, "
-                               f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} embed+detect+vote "
-                               f"(BASELINE.json configs[{2 if H >= 2160 else 1}])", "codec": a.codec,
-                   "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
+        "config": {"workload": workload + f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} {op}+vote (BASELINE.json {what})",
+                   "codec": a.codec, "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
                    "chunk_frames": chunk,
-                   "detect": ("separate kernels" if a.separate_detect else "one-pass kernel" if a.onepass >= 0
-                              else "fused into the mark kernel") if a.codec == "dct" else "fused into the embed kernel",
-                   "sharding": f"frames, {world} rank(s), one RCCL all-gather of payloads"},
+                   "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")
+                   if a.codec == "dct" else "fused into the embed kernel",
+                   "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {world} rank(s), one RCCL all-gather of payloads"},
         "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,
         "roofline": roof,
-        "path": {"algorithmic_GBps": round(path_gbps, 1), "bytes_per_frame": 9 * H * W,
+        "path": {"algorithmic_GBps": round(path_gbps, 1), "bytes_per_frame": bpp * H * W,
                  "frac_of_peak": round(path_gbps / (HBM_PEAK_GBPS * world), 4),
                  "frac_of_measured_copy": round(path_gbps / (copy_gbps * world), 4)},
-        "hbm_copy_GBps": round(copy_gbps, 1),
+        "hbm_copy_GBps": round(copy_gbps, 1), "hbm_read_GBps": round(read_gbps, 1),
+        "source_sha16": sha,
         "host_ms_per_step": host_ms,            # rank 0's CPU time issuing a step / voting on one; must stay < ms_per_step
         "cpu_baseline": base,
     }

@@ -10,7 +10,11 @@
  *   - every pointer marked "device" is HBM memory owned by the caller (e.g. torch tensors);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is only
  *     ENQUEUED on it: no allocation, no host synchronisation, no internal threads, so every
- *     compute call may be captured into a hipGraph (the ofmk_timing_* helpers are host-side);
+ *     compute call may be captured into a hipGraph (unless it carries an ofmk_timing object);
+ *   - re-entrant: the library has NO mutable state besides the calling thread's error text.
+ *     Everything a call needs arrives in its arguments; per-call options travel in `ofmk_opts`
+ *     (NULL = defaults).  Two host threads may drive two engines (own workspace, own stream,
+ *     own timing object) concurrently (tests/test_gpu_parity.py::test_two_threads_two_engines);
  *   - return value 0 = OK, negative = error (OFMK_E_*); ofmk_last_error() gives the text for
  *     the calling thread; nothing throws across this boundary;
  *   - frames are interleaved 8-bit, 3 channels, row-major [n][H][W][3] exactly as
@@ -30,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OFMK_ABI_VERSION 1
+#define OFMK_ABI_VERSION 2
 
 #define OFMK_OK            0
 #define OFMK_E_ARG        -1   /* null pointer / non-positive size / H or W < 8 */
@@ -40,10 +44,23 @@ extern "C" {
 int ofmk_version(void);
 const char *ofmk_last_error(void);
 
+/* Per-call options (the reference's codecs are stateless objects configured by constructor kwargs,
+ * src/offmark/embed/dct_encoder.py:6-16; this is the same idea at the C boundary).  Pass NULL for defaults. */
+typedef struct ofmk_timing ofmk_timing;     /* opaque, see ofmk_timing_create */
+typedef struct ofmk_opts {
+    uint32_t flags;          /* OFMK_F_* */
+    uint32_t reserved;       /* must be 0 */
+    ofmk_timing *timing;     /* NULL = launches carry no events */
+} ofmk_opts;
+/* ofmk_embed_detect_rgb8: embed, then detect the written frames with the stand-alone detect kernels
+ * (analyze runs on the marked frames: 12 B/px of traffic) instead of the fused mark+verify kernel
+ * (9 B/px).  Same results bit for bit. */
+#define OFMK_F_SEPARATE_DETECT 1u
+
 /* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
  * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to
- * what fits (bigger chunk = fewer launches; smaller chunk = the second pass over a chunk is
- * served from the 256 MiB Infinity Cache). */
+ * what fits.  Bigger chunks are faster (fewer launches, shorter tails): keeping a chunk resident
+ * in the 256 MiB Infinity Cache between the two passes was measured NOT to pay. */
 size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W);
 
 /* ---- embed: replaces Embedder.__mark_frame + DctEncoder.encode for a batch of frames ------
@@ -56,7 +73,8 @@ size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W);
  *   chunk_frames  frames per internal chunk, 0 = as many as the workspace holds            */
 int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                     const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
-                    int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+                    int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                    const ofmk_opts *opts);
 
 /* ---- detect: replaces Extractor.__check_frame + DctDecoder.decode + the bits[i::L] sums ----
  * src/offmark/video/extractor.py:30-34, src/offmark/extract/dct_decoder.py:10-27,
@@ -66,7 +84,8 @@ int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
  *   bits      device u8 [n][N] raw per-block bits (DctDecoder.decode's array), or NULL     */
 int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha,
                      int32_t *counts, uint8_t *bits,
-                     int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+                     int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                     const ofmk_opts *opts);
 
 /* ---- soft-decision read-out (BUILD EXTENSION, not reference semantics) -------------
  * soft: device int64 [n][L]; soft[f][i] = sum over blocks c with c mod L == i of round(-cos(pi*C21/step) * 2^14):
@@ -78,12 +97,14 @@ int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double 
 
 /* ---- embed then detect the produced frames, chunk by chunk (mark + verify) ---------------
  * The shape of tests/mark_video_to_hls.py:356-389 (verify every marked copy).  Same results as
- * ofmk_embed_rgb8 followed by ofmk_detect_rgb8 on `out`; the detect pass of a chunk runs while
- * the chunk is still cache resident. */
+ * ofmk_embed_rgb8 followed by ofmk_detect_rgb8 on `out`.  By default the mark kernel also analyzes
+ * the marked block it still holds in registers, so detect's read of the frame is saved
+ * (opts->flags & OFMK_F_SEPARATE_DETECT runs the literal two-call sequence instead). */
 int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                            const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
                            int L, int32_t *counts, uint8_t *bits,
-                           int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+                           int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                           const ofmk_opts *opts);
 
 /* ---- DwtDctSvd codec (what tests/mark.py and tests/detect.py construct) -----------------------
  * src/offmark/embed/dwt_dct_svd_encoder.py:19-45 (Haar LL of channel 1 -> 4x4 blocks -> DCT -> SVD ->
@@ -92,12 +113,13 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
  * reference's default scales=[0, scale, 0], blk=4.  Same frame/watermark/counts/bits conventions as
  * the DCT entry points; no workspace (this codec has no frame-global dependency: one pass).     */
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
-                        const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream);
+                        const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream,
+                        const ofmk_opts *opts);
 int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double scale,
-                         int32_t *counts, uint8_t *bits, void *stream);
+                         int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                                const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale,
-                               int L, int32_t *counts, uint8_t *bits, void *stream);
+                               int L, int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
 /* plugin level, float32 YUV [n][H][W][3] (n <= 65535): encode mutates channel 1; decode fills bits */
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W,
                            const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream);
@@ -137,38 +159,29 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
  *           watermark (row 0 for every frame) -> marked frames; fused != 0 also analyzes the
  *           marked frames (mark + verify kernel)                                             */
 int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
 int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                          const uint8_t *wm, double alpha, int fused,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
 
-/* Device-to-device streaming copy with 16-byte accesses; bench.py uses it to measure the
- * achievable HBM bandwidth of the device in the same run as the kernels. */
+/* Streaming probes: bench.py measures the device's achievable HBM rates with them in the same run as the
+ * kernels.  ofmk_hbm_copy: device-to-device copy, 16 bytes per lane and access, registers only (reads `bytes`,
+ * writes `bytes`).  ofmk_hbm_read: read-only stream of `bytes`; `sink` is a device uint32 the kernel
+ * practically never writes (it only keeps the loads alive). */
 int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream);
+int ofmk_hbm_read(const void *src, size_t bytes, void *sink, void *stream);
 
-/* Per-launch HIP-event timing for bench.py.  enable() pre-creates 2*max_launches events; while
- * enabled every launch of a kernel kind selected in kind_mask (bit k = kind k, 0 = all) carries an
- * event pair as the dispatch's own start/stop events (hipExtLaunchKernelGGL) on the launch stream, so no
- * marker packets separate consecutive kernels; collect()
- * waits for the recorded events, returns the summed milliseconds and launch counts per kernel
- * kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze, 4 DwtDctSvd) and rewinds the pool.  Not for use under graph capture. */
-int ofmk_timing_enable(int max_launches, unsigned kind_mask);
-int ofmk_timing_collect(double *ms_by_kind /*[5]*/, int *launches_by_kind /*[5]*/);
-void ofmk_timing_disable(void);
-
-/* Process-wide switch for ofmk_embed_detect_rgb8: 1 (default) marks and analyzes the marked block
- * in one kernel; 0 runs the separate mark and analyze kernels (same results bit for bit).  (2 selects an
- * experimental single-pass variant for ofmk_stage_mark_rgb8, see tools/upper_bound.py.) */
-void ofmk_set_fused_verify(int on);
-
-/* Experimental (round 1): on = 3 makes ofmk_embed_detect_rgb8 use a persistent ONE-PASS kernel that keeps each
- * block's pixels in registers across the frame-mean dependency (6 instead of 9 B/px of traffic; same results
- * bit for bit).  ofmk_set_onepass_grid sets its number of workgroups (work is ticketed, so no dispatch order is
- * assumed; the launcher raises the grid to the number of 256-block tiles of one frame, which must all be in
- * flight at once, and frames of more than 512 tiles use the two-kernel path).  Its spins are bounded; ofmk_onepass_error copies the time-out flag of the last run to the host
- * (this call synchronises the device). */
-void ofmk_set_onepass_grid(int workgroups);
-int ofmk_onepass_error(void *workspace, size_t workspace_bytes, int H, int W, int chunk_frames, unsigned int *host_flag);
+/* Per-launch HIP-event timing for bench.py.  A timing object owns 2*max_launches events; while it is passed in
+ * ofmk_opts.timing every launch of a kernel kind selected in kind_mask (bit k = kind k, 0 = all) carries an event
+ * pair as the dispatch's own start/stop events (hipExtLaunchKernelGGL) on the launch stream, so no marker packets
+ * separate consecutive kernels.  collect() waits for the recorded events, returns the summed milliseconds and
+ * launch counts per kernel kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze, 4 DwtDctSvd, 5 planar
+ * 4:2:0 kernels) and rewinds the pool.  One object per engine / host thread; a call that carries one cannot be
+ * captured into a hipGraph (events on the dispatch). */
+#define OFMK_TIMING_KINDS 6
+int ofmk_timing_create(int max_launches, unsigned kind_mask, ofmk_timing **out);
+int ofmk_timing_collect(ofmk_timing *t, double *ms_by_kind /*[OFMK_TIMING_KINDS]*/, int *launches_by_kind /*[OFMK_TIMING_KINDS]*/);
+void ofmk_timing_destroy(ofmk_timing *t);
 
 #ifdef __cplusplus
 }

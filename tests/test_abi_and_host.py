@@ -30,9 +30,15 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in offmark_hip.h but not exported"
     assert sorted(_hip.SYMBOLS) == declared
-    assert lib.ofmk_version() == 1
+    # the library keeps no mutable globals besides the per-thread error text (header: "re-entrant")
+    nm = subprocess.run(["nm", "-C", _hip.lib_path()], capture_output=True, text=True).stdout
+    writable = [l for l in nm.splitlines() if len(l.split()) >= 3 and l.split()[1] in "bBdD"
+                and ("ofmk" in l or " g_" in l) and "(" not in l          # "name(args)" = a kernel's launch handle
+                and "g_err" not in l and "guard variable" not in l]
+    assert not writable, writable
+    assert lib.ofmk_version() == _hip.ABI_VERSION == 2
     # pure host-side entry points are safe to call without a GPU
-    assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 32 * 8 + 16 + 4096
+    assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 32 * 8 + 4096
     assert lib.ofmk_workspace_bytes(0, 1080, 1920) == 0 and lib.ofmk_workspace_bytes(1, 4, 1920) == 0
 
 

@@ -1,11 +1,19 @@
 """GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the golden vectors.
 
-Tolerances (the reference pins none for this path; OpenCV arithmetic is unpinned):
+What is compared with what: the oracle (oracle/offmark_oracle.py) reproduces bit for bit the vectors in
+tests/golden/, which were captured by running the reference's own Python modules with the oracle's restated
+cv2.dct / cv2.idct / cvtColor supplied as a stand-in module (OpenCV is not installed: tools/make_golden.py).
+So these tests pin the reference's control flow and scalar semantics; OpenCV's own float rounding is
+PARITY UNPINNED.
+
+Tolerances (the reference pins none for this path).  Budgets are ~10x what is measured
+(profiles/r2_parity_stats.txt; every comparison made by this file is also logged, see _MEASURED):
   payload after DeShuffler ............ bit-exact
-  raw per-block bits .................. <= 0.5 % mismatch vs oracle (ulp-level threshold flips)
+  raw per-block bits .................. <= 1e-4 of the blocks (floor: 1 block) vs oracle (ulp-level threshold flips)
   Y DC, C21 ........................... <= 1e-3 absolute on 0..255-scale data
-  luminance / texture masks ........... equal to 1e-12 except on <= 0.5 % threshold-flip blocks
-  marked u8 pixels .................... <= 1 LSB, on <= 0.1 % of samples, over "sign-determined" blocks
+  luminance / texture masks ........... equal to 1e-9 relative except on <= 1e-4 threshold-flip blocks
+  marked u8 pixels .................... <= 1 LSB, on <= 1e-5 of the samples (floor: 1 sample), over
+                                        "sign-determined" blocks
 
 Sign-ambiguous blocks: the reference multiplies the quantised magnitude by np.sign(C21)
 (dct_encoder.py:33-35).  Where |C21| is below the coefficient tolerance (1e-3) -- typical for
@@ -41,10 +49,40 @@ def cuda(a):
 
 
 def budget(n, frac, floor=1):
-    return max(floor, int(np.ceil(n * frac)))
+    return max(floor, int(np.floor(n * frac)))
 
 
 C21_TOL = 1e-3
+PIXEL_FRAC = 1e-5        # measured 2.6e-7 (profiles/r2_parity_stats.txt)
+BITS_FRAC = 1e-4         # measured 0
+
+# every pixel / raw-bit comparison of this module: (kind, test id, differing, compared); written to
+# gpurun_out/parity_measured.json at the end of the session so the budgets above stay honest
+_MEASURED = []
+
+
+def _log(kind, bad, n):
+    _MEASURED.append((kind, os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], int(bad), int(n)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_measured():
+    yield
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tot = {}
+    for kind, _, bad, n in _MEASURED:
+        t = tot.setdefault(kind, [0, 0])
+        t[0] += bad
+        t[1] += n
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_measured.json"), "w") as f:
+            json.dump({"totals": {k: dict(differing=v[0], compared=v[1], frac=v[0] / max(v[1], 1)) for k, v in tot.items()},
+                       "worst": sorted(({"kind": k, "test": t, "differing": b, "compared": n} for k, t, b, n in _MEASURED if b),
+                                       key=lambda d: -d["differing"] / max(d["compared"], 1))[:40]}, f, indent=1)
+    except OSError:
+        pass
 
 
 def oracle_embed_debug(frame, wm, alpha):
@@ -69,13 +107,15 @@ def assert_pixels_close(got, ref, mask=None):
         d = d[mask]
     if d.size == 0:
         return
+    _log("pixels", (d > 0).sum(), d.size)
     assert d.max() <= 1, f"max pixel diff {d.max()}"
-    assert (d > 0).sum() <= budget(d.size, 1e-3), f"{(d > 0).sum()} of {d.size} samples differ"
+    assert (d > 0).sum() <= budget(d.size, PIXEL_FRAC), f"{(d > 0).sum()} of {d.size} samples differ"
 
 
 def assert_bits_close(got, ref, nblk):
     mism = int((got.reshape(-1) != ref.reshape(-1)).sum())
-    assert mism <= budget(nblk, 5e-3), f"{mism} raw bits differ of {nblk}"
+    _log("raw_bits", mism, nblk)
+    assert mism <= budget(nblk, BITS_FRAC), f"{mism} raw bits differ of {nblk}"
 
 
 def degen(g, counts, n_bits):
@@ -127,15 +167,19 @@ def test_debug_planes_against_oracle(eng, case):
         bad = np.abs(d[k] - ref) > 1e-9 * np.maximum(1, np.abs(ref))
         # texture ramp carries the float32 rounding of eh: allow 2e-6 relative there
         bad &= np.abs(d[k] - ref) > 2e-6
-        assert bad.sum() <= budget(nblk, 5e-3, floor=0 if nblk < 200 else 1), (k, int(bad.sum()))
+        _log("mask_" + k, bad.sum(), nblk)
+        assert bad.sum() <= budget(nblk, BITS_FRAC, floor=0), (k, int(bad.sum()))
     same = np.abs(d["step"] - alpha * enc.debug["mask"]) <= 1e-4
     amb = np.abs(enc.debug["c21_pre"]) <= C21_TOL
     post_ok = np.where(amb, np.abs(np.abs(d["c21_post"]) - np.abs(enc.debug["c21_post"])) <= 2e-3,
                        np.abs(d["c21_post"] - enc.debug["c21_post"]) <= 2e-3)
-    # an exactly-zero coefficient must stay zero on both sides (np.sign(0) == 0)
-    assert np.array_equal(d["c21_post"][enc.debug["c21_pre"] == 0] == 0,
-                          np.ones(int((enc.debug["c21_pre"] == 0).sum()), bool)) or True
-    assert (~(same & post_ok)).sum() <= budget(nblk, 5e-3, floor=0 if nblk < 200 else 1)
+    # an exactly-zero coefficient must stay exactly zero (np.sign(0) == 0, dct_encoder.py:33-35: the bit is lost
+    # there): wherever the oracle's C21 is an exact zero, so is the kernel's, before and after the quantiser
+    zero = enc.debug["c21_pre"] == 0
+    assert (d["c21_pre"][zero] == 0).all() and (d["c21_post"][zero] == 0).all()
+    assert (enc.debug["c21_post"][zero] == 0).all()
+    _log("step_or_c21_post", (~(same & post_ok)).sum(), nblk)
+    assert (~(same & post_ok)).sum() <= budget(nblk, BITS_FRAC, floor=0)
 
 
 @pytest.mark.parametrize("seed", [2000, 2001, 2003])
@@ -231,16 +275,17 @@ def test_yuv_plugin_boundary(eng):
     assert got is arg                                              # mutates and returns its input
     assert np.array_equal(got[:, :, 0], yuv[:, :, 0]) and np.array_equal(got[:, :, 2], yuv[:, :, 2])
     close = np.abs(got[:, :, 1] - ref[:, :, 1]) <= 2e-3
-    assert (~close).sum() <= 64 * budget(1200, 5e-3)               # a flipped block moves its 64 samples
+    assert (~close).sum() <= 64 * budget(1200, BITS_FRAC)          # a flipped block moves its 64 samples
     bits = DctDecoder(alpha=20).decode(ref)
     ref_bits = orc.DctDecoderOracle(alpha=20).decode(ref)
     assert bits.dtype == np.float64 and bits.shape == ref_bits.shape == (1, 1200)
     assert_bits_close(bits, ref_bits, 1200)
     y = yuv[:, :, 0]
-    assert np.abs(enc.luminance_mask(y) - orc.luminance_mask_vec(y)).max() < 1e-6 or True
     lum_bad = np.abs(enc.luminance_mask(y) - orc.luminance_mask_vec(y)) > 1e-6
     tex_bad = np.abs(enc.texture_mask(y) - orc.texture_mask_vec(y)) > 2e-6
-    assert lum_bad.sum() <= 6 and tex_bad.sum() <= 6
+    _log("mask_lum", lum_bad.sum(), 1200)
+    _log("mask_tex", tex_bad.sum(), 1200)
+    assert lum_bad.sum() == 0 and tex_bad.sum() == 0
 
 
 def test_abi_error_codes(eng):
@@ -251,11 +296,11 @@ def test_abi_error_codes(eng):
     ws = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
     wm = torch.zeros(4, dtype=torch.uint8, device="cuda")
     s = _hip.current_stream()
-    assert lib.ofmk_embed_rgb8(None, f.data_ptr(), 1, 16, 16, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s) == -1
-    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, 4, 16, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s) == -1
+    assert lib.ofmk_embed_rgb8(None, f.data_ptr(), 1, 16, 16, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s, None) == -1
+    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, 4, 16, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s, None) == -1
     assert b"at least 8" in lib.ofmk_last_error()
-    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, 16, 16, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), 8, s) == -2
-    assert lib.ofmk_detect_rgb8(f.data_ptr(), 1, 16, 16, 0, 20.0, ws.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), s) == -1
+    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, 16, 16, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), 8, s, None) == -2
+    assert lib.ofmk_detect_rgb8(f.data_ptr(), 1, 16, 16, 0, 20.0, ws.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), s, None) == -1
     assert lib.ofmk_workspace_bytes(0, 16, 16) == 0 and lib.ofmk_workspace_bytes(1, 16, 16) > 0
     with pytest.raises(_hip.HipError):
         _hip.check(-1)
@@ -266,17 +311,12 @@ def test_fused_verify_kernel_equals_separate_kernels(eng):
     bit for bit (same arithmetic on the same rounded pixels)."""
     import torch
     from offmark import _hip
-    lib = _hip.load()
     frames = cuda(np.stack([orc.synthetic_frame(240, 320, 1001 + i) for i in range(5)] ))
     nat = np.load(os.path.join(GOLDEN, "frame63_crop_qr_k0_a20.npz"))["frame"]
     wm = orc.shuffle_generate(P8, (1, 1200), 0)
-    try:
-        lib.ofmk_set_fused_verify(1)
-        o1, c1, b1 = eng.embed_detect(frames, wm, L=8, want_bits=True)
-        lib.ofmk_set_fused_verify(0)
-        o2, c2, b2 = eng.embed_detect(frames, wm, L=8, want_bits=True)
-    finally:
-        lib.ofmk_set_fused_verify(1)
+    o1, c1, b1 = eng.embed_detect(frames, wm, L=8, want_bits=True)
+    sep = type(eng)(opts=_hip.Opts(_hip.F_SEPARATE_DETECT, 0, None))       # per-engine option, no process-wide switch
+    o2, c2, b2 = sep.embed_detect(frames, wm, L=8, want_bits=True)
     assert torch.equal(o1, o2) and torch.equal(c1, c2) and torch.equal(b1, b2)
     wmn = orc.shuffle_generate(P8, (1, nat.shape[0] * nat.shape[1] // 64), 0)
     o3, c3, b3 = eng.embed_detect(cuda(nat[None]), wmn, L=8, want_bits=True)
@@ -348,6 +388,95 @@ def test_4k_frame_against_oracle(eng):
     assert np.array_equal(DeShuffler(key=0).set_shape((8,)).degenerate_counts(counts[0].cpu().numpy(), 129600), P8)
 
 
+def test_4k_multi_chunk_batch(eng):
+    """BASELINE config 3 shape (4K frames processed in several internal chunks): 100 frames with chunk_frames=40
+    (chunks of 40, 40, 20) must equal the single-chunk result bit for bit, every frame must recover its own
+    payload, and chunk boundaries must not leak state (per-frame means, counts)."""
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.synthetic import synthetic_frames
+    H, W, n = 2160, 3840, 100
+    N = H * W // 64
+    base = synthetic_frames(10, H, W, seed=3100)
+    frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device="cuda")
+    for i in range(n):                                              # distinct frames: rolled by whole blocks
+        frames[i] = torch.roll(base[i % 10], shifts=(8 * (i // 10), 16 * (i // 10)), dims=(0, 1))
+    payloads = np.array([[int(b) for b in format(s, "08b")] for s in (0x65, 0x9a, 0x3c)])
+    wm = np.stack([orc.shuffle_generate(p, (N,), 0) for p in payloads])
+    rows = (np.arange(n) % 3).astype(np.int32)
+    chunked = type(eng)(chunk_frames=40)
+    out_c, counts_c, _ = chunked.embed_detect(frames, wm, L=8, wm_row=rows)
+    whole = type(eng)(chunk_frames=n)
+    out_w, counts_w, _ = whole.embed_detect(frames, wm, L=8, wm_row=rows)
+    assert torch.equal(out_c, out_w) and torch.equal(counts_c, counts_w)
+    got = DeShuffler(key=0).set_shape((8,)).degenerate_counts(counts_c.cpu().numpy(), N)
+    assert np.array_equal(got, payloads[rows])
+    c_det, _ = chunked.detect(out_c, 8)                              # stand-alone detect, chunked, agrees with the fused verify
+    assert torch.equal(c_det, counts_c)
+    assert torch.equal(out_c[..., 2], frames[..., 2])
+    # one frame of the batch against the oracle (a frame in the LAST, shorter chunk)
+    k = 93
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(wm[rows[k]][None])
+    f_host = frames[k].cpu().numpy()
+    ref = orc.mark_frame(f_host, enc)
+    okb = np.abs(enc.debug["c21_pre"]) > C21_TOL
+    assert_pixels_close(out_c[k].cpu().numpy(), ref, np.kron(okb, np.ones((8, 8), bool)))
+
+
+def test_two_threads_two_engines(eng):
+    """include/offmark_hip.h: the library has no mutable state besides the per-thread error text.  Two host threads
+    drive two engines (own workspace, stream, options and timing object) at the same time; each must get exactly
+    what it gets alone, the per-thread error texts must not mix, and each timing object must see only its own
+    engine's launches."""
+    import threading
+    import torch
+    from offmark import _hip
+    from offmark.synthetic import synthetic_frames
+    lib = _hip.load()
+    H, W, n = 240, 320, 24
+    N = H * W // 64
+    fa, fb = synthetic_frames(n, H, W, seed=11), synthetic_frames(n, 120, 200, seed=12)
+    wma = orc.shuffle_generate(P8, (1, N), 0)
+    wmb = orc.shuffle_generate(P8[::-1].copy(), (1, 120 * 200 // 64), 5)
+    ref_a = eng.embed_detect(fa, wma, L=8, want_bits=True)
+    ref_b = type(eng)(opts=_hip.Opts(_hip.F_SEPARATE_DETECT, 0, None)).embed_detect(fb, wmb, L=8, alpha=10, want_bits=True)
+    torch.cuda.synchronize()
+    results, errors = {}, {}
+
+    def work(name, frames, wm, alpha, flags, bad_h, bad_ws, want_rc, want_txt):
+        try:
+            torch.cuda.set_device(0)
+            timing = _hip.Timing(64 * 8)
+            e = type(eng)(opts=timing.opts(flags))
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    got = e.embed_detect(frames, wm, L=8, alpha=alpha, want_bits=True)
+                    # a failing call on this thread: its error text must be this thread's own
+                    rc = lib.ofmk_embed_rgb8(frames.data_ptr(), frames.data_ptr(), 1, bad_h, 16, frames.data_ptr(), 1, None,
+                                             20.0, 0, frames.data_ptr(), bad_ws, stream.cuda_stream, None)
+                    txt = lib.ofmk_last_error()
+                    assert rc == want_rc and want_txt in txt, (rc, txt)
+            stream.synchronize()
+            results[name] = (got, timing.collect())
+            timing.close()
+        except Exception as exc:                                     # surfaced by the main thread
+            errors[name] = exc
+
+    # both failing calls are rejected before anything is enqueued (H < 8; a workspace of 8 bytes)
+    ta = threading.Thread(target=work, args=("a", fa, wma, 20, 0, 4, 1 << 20, -1, b"at least 8"))
+    tb = threading.Thread(target=work, args=("b", fb, wmb, 10, _hip.F_SEPARATE_DETECT, 16, 8, -2, b"workspace smaller"))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errors, errors
+    for name, ref in (("a", ref_a), ("b", ref_b)):
+        got, _ = results[name]
+        assert all(torch.equal(x, y) for x, y in zip(got, ref)), name
+    ka, kb = results["a"][1], results["b"][1]
+    assert ka["mark_fused"]["launches"] == 20 and ka["mark"]["launches"] == 0 and ka["analyze"]["launches"] == 20
+    assert kb["mark"]["launches"] == 20 and kb["mark_fused"]["launches"] == 0 and kb["analyze"]["launches"] == 40
+
+
 def test_stage_entry_points_and_copy(eng):
     import torch
     from offmark import _hip
@@ -359,15 +488,24 @@ def test_stage_entry_points_and_copy(eng):
     out = torch.empty_like(frames)
     s = _hip.current_stream()
     wm_dev = cuda(wm.astype(np.uint8))
-    _hip.check(lib.ofmk_stage_analyze_rgb8(frames.data_ptr(), 3, 64, 96, ws.data_ptr(), ws.numel(), s))
+    _hip.check(lib.ofmk_stage_analyze_rgb8(frames.data_ptr(), 3, 64, 96, ws.data_ptr(), ws.numel(), s, None))
     _hip.check(lib.ofmk_stage_mark_rgb8(frames.data_ptr(), out.data_ptr(), 3, 64, 96, wm_dev.data_ptr(), 20.0, 0,
-                                        ws.data_ptr(), ws.numel(), s))
+                                        ws.data_ptr(), ws.numel(), s, None))
     assert torch.equal(out, ref)
     a = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
     b = torch.zeros_like(a)
     _hip.check(lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), a.numel() * 4, s))
     assert torch.equal(a, b)
     assert lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), 7, s) == -1
+    for nbytes in (16, 16 * 1023, 16 * 1025, 16 * 5000 + 16):            # ragged last span of the copy
+        b.zero_()
+        _hip.check(lib.ofmk_hbm_copy(a.data_ptr(), b.data_ptr(), nbytes, s))
+        assert torch.equal(a[: nbytes // 4], b[: nbytes // 4]) and not b[nbytes // 4:].any()
+    sink = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _hip.check(lib.ofmk_hbm_read(a.data_ptr(), a.numel() * 4, sink.data_ptr(), s))
+    _hip.check(lib.ofmk_hbm_read(a.data_ptr(), 16 * 2049, sink.data_ptr(), s))
+    torch.cuda.synchronize()
+    assert lib.ofmk_hbm_read(a.data_ptr(), 8, sink.data_ptr(), s) == -1
 
 
 def test_config4_segments_with_own_payloads(eng):
@@ -545,12 +683,12 @@ def test_long_and_oversized_payloads_and_empty_inputs(eng):
     ws = eng.workspace(H, W, 1)
     wm = cuda(orc.shuffle_generate(P8, (1, N), 0).astype(np.uint8))
     s = _hip.current_stream()
-    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 0, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s) == -1
-    assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 0.0, s) == -1
-    assert lib.ofmk_svd_detect_rgb8(f.data_ptr(), 1, H, W, 8, 15.0, None, None, s) == -1
+    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 0, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s, None) == -1
+    assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 0.0, s, None) == -1
+    assert lib.ofmk_svd_detect_rgb8(f.data_ptr(), 1, H, W, 8, 15.0, None, None, s, None) == -1
     assert lib.ofmk_payloads_from_counts(None, 1, 8, N, None, None, s) == -1
     unaligned = torch.empty(ws.numel() + 1, dtype=torch.uint8, device="cuda")[1:]
-    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 20.0, 0, unaligned.data_ptr(), ws.numel(), s) == -1
+    assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 20.0, 0, unaligned.data_ptr(), ws.numel(), s, None) == -1
     assert b"256-byte aligned" in lib.ofmk_last_error()
 
 
@@ -612,40 +750,29 @@ def test_full_natural_1080p_frame(eng):
     # our own marked frame decodes to the same bits as the reference's on the sign-determined blocks
     det = mask[::8, ::8].reshape(-1)
     own = bits[0].cpu().numpy()
-    assert (own[det] != ref_bits[det]).sum() <= budget(32400, 5e-3)
-    # and the raw bit-error rate against the embedded watermark is the same as the reference's to within 0.5 %
-    assert abs((own != wm.reshape(-1)).mean() - (ref_bits != wm.reshape(-1)).mean()) < 5e-3
-
-
-def test_onepass_persistent_kernel_equals_two_kernel_path(eng):
-    """The ticketed one-pass embed+verify kernel (pixels stay in registers across the frame-mean dependency)
-    must reproduce the analyze + fused-mark path bit for bit, for any grid size, and never time out."""
-    import ctypes
-    import torch
-    from offmark import _hip
-    from offmark.synthetic import synthetic_frames
-    lib = _hip.load()
-    for (H, W, n) in [(240, 320, 37), (1080, 1920, 24), (30, 44, 5)]:
-        N = H * W // 64
-        frames = synthetic_frames(n, H, W, seed=900 + H)
-        payloads = np.stack([[int(b) for b in format(s + 1, "08b")] for s in range(4)])
-        wm = np.stack([orc.shuffle_generate(p, (N,), 0) for p in payloads])
-        rows = (np.arange(n) % 4).astype(np.int32)
-        ref_out, ref_counts, ref_bits = eng.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
-        try:
-            for grid in (1, 7, 768, 4096):      # 1 and 7 are raised to the tiles of one frame by the launcher
-                lib.ofmk_set_fused_verify(3)
-                lib.ofmk_set_onepass_grid(grid)
-                out, counts, bits = eng.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
-                torch.cuda.synchronize()
-                ws = eng.workspace(H, W, eng._chunk(n, H, W))
-                flag = ctypes.c_uint(7)
-                _hip.check(lib.ofmk_onepass_error(ws.data_ptr(), ws.numel(), H, W, eng._chunk(n, H, W), ctypes.byref(flag)))
-                assert flag.value == 0, f"spin timed out (grid {grid})"
-                assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(bits, ref_bits), (H, W, grid)
-        finally:
-            lib.ofmk_set_fused_verify(1)
-            lib.ofmk_set_onepass_grid(0)
+    _log("raw_bits_own_marked", (own[det] != ref_bits[det]).sum(), int(det.sum()))
+    assert (own[det] != ref_bits[det]).sum() <= budget(32400, BITS_FRAC)
+    # the sign-ambiguous blocks (~15 % of this frame) are excluded from the pixel comparison above; what the
+    # reference defines for them is the quantised MAGNITUDE of C21 (dct_encoder.py:30-35), hence the decoded bit:
+    # check it on every one of them.  The only other admissible outcome is "exact zero on one side, rounding
+    # noise on the other" (np.sign(0) == 0 keeps a zero, noise gets +-step), which must be rare.
+    dbg = enc.debug
+    d = eng.debug_planes(cuda(nat), alpha=20, wm=wm)
+    amb = np.abs(dbg["c21_pre"]) <= C21_TOL
+    assert amb.sum() == n_amb
+    mag_ok = np.abs(np.abs(d["c21_post"]) - np.abs(dbg["c21_post"])) <= 2e-3
+    zero_vs_noise = (dbg["c21_pre"] == 0) != (d["c21_pre"] == 0)
+    _log("ambiguous_magnitude", (amb & ~mag_ok & ~zero_vs_noise).sum(), n_amb)
+    _log("ambiguous_zero_vs_noise", (amb & zero_vs_noise).sum(), n_amb)
+    assert (amb & ~mag_ok & ~zero_vs_noise).sum() == 0
+    assert (amb & zero_vs_noise).sum() <= budget(n_amb, 1e-2)
+    assert (d["c21_post"][d["c21_pre"] == 0] == 0).all()           # the kernel's own exact zeros stay zero
+    # the ambiguous blocks of our own marked frame decode to the bit the quantised magnitude carries
+    nz = amb.reshape(-1) & ~zero_vs_noise.reshape(-1) & (dbg["c21_pre"].reshape(-1) != 0)
+    _log("raw_bits_own_marked_ambiguous", (own[nz] != ref_bits[nz]).sum(), int(nz.sum()))
+    assert (own[nz] != ref_bits[nz]).sum() <= budget(int(nz.sum()), 1e-3)
+    # and the raw bit-error rate against the embedded watermark is the same as the reference's to within 0.1 %
+    assert abs((own != wm.reshape(-1)).mean() - (ref_bits != wm.reshape(-1)).mean()) < 1e-3
 
 
 def test_soft_decision_extension(eng):
@@ -698,7 +825,9 @@ def test_grayscale_content_where_every_block_is_sign_ambiguous(eng):
     both_zero = (dbg["c21_pre"] == 0) & (d["c21_pre"] == 0)
     mag_ok = np.abs(np.abs(d["c21_post"]) - np.abs(dbg["c21_post"])) <= 2e-3
     zero_vs_noise = ((dbg["c21_pre"] == 0) != (d["c21_pre"] == 0))
+    _log("gray_zero_vs_noise", zero_vs_noise.sum(), 1200)
     assert (~(mag_ok | zero_vs_noise)).sum() == 0 and zero_vs_noise.sum() <= budget(1200, 2e-2)
+    assert (d["c21_post"][both_zero] == 0).all()
     enc = orc.DctEncoderOracle(alpha=20)
     enc.read_wm(wm)
     ref = orc.mark_frame(frame, enc)
@@ -707,6 +836,7 @@ def test_grayscale_content_where_every_block_is_sign_ambiguous(eng):
     deg = DeShuffler(key=0).set_shape((8,))
     assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), 1200), P8)
     assert np.array_equal(orc.deshuffle(ref_bits, 8, 0), P8)
+    _log("gray_raw_bits", (bits[0].cpu().numpy() != ref_bits).sum(), 1200)
     assert (bits[0].cpu().numpy() != ref_bits).sum() <= budget(1200, 2e-2)
     assert np.abs(marked[0].cpu().numpy().astype(int) - ref.astype(int)).max() <= 2 * 60     # at most a flipped +-step pattern
 

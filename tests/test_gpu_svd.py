@@ -1,9 +1,13 @@
 """GPU parity for the DwtDctSvd codec -- the pair tests/mark.py and tests/detect.py construct.
 
-Tolerances (none pinned upstream; PyWavelets/OpenCV/LAPACK float arithmetic unpinned):
+The svd_*.npz vectors were captured by running the reference's own modules with the oracle's restated pywt /
+cv2 primitives supplied as stand-in modules (neither library is installed): they pin the reference's control
+flow; PyWavelets' and OpenCV's float arithmetic is PARITY UNPINNED (np.linalg.svd is the real LAPACK).
+
+Tolerances (none pinned upstream), ~10x what is measured (profiles/r2_parity_stats.txt: 2.1e-6 and 0):
   payload after DeShuffler ... bit-exact
-  raw per-block bits ......... <= 0.5 % mismatch vs oracle
-  marked u8 pixels ........... <= 1 LSB on <= 0.1 % of samples over "determined" blocks: a block is
+  raw per-block bits ......... <= 1e-4 of the blocks (floor: 1 block) vs oracle
+  marked u8 pixels ........... <= 1 LSB on <= 2e-5 of the samples (floor: 1) over "determined" blocks: a block is
      skipped when its top singular value is within 1e-3 of a multiple of the quantisation step
      (s0 // scale flips on the last float bits and moves s0 by a whole step) or when its two largest
      singular values are within 1e-3 relative (the rank-1 direction u0 v0^T is then not defined).
@@ -34,7 +38,7 @@ def cuda(a):
 
 
 def budget(n, frac, floor=1):
-    return max(floor, int(np.ceil(n * frac)))
+    return max(floor, int(np.floor(n * frac)))
 
 
 def determined_pixels(frame, wm, scale=15):
@@ -54,7 +58,7 @@ def assert_pixels_close(got, ref, mask):
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))[mask]
     if d.size:
         assert d.max() <= 1, f"max pixel diff {d.max()}"
-        assert (d > 0).sum() <= budget(d.size, 1e-3), f"{(d > 0).sum()} of {d.size} samples differ"
+        assert (d > 0).sum() <= budget(d.size, 2e-5), f"{(d > 0).sum()} of {d.size} samples differ"
 
 
 @pytest.mark.parametrize("case", svd_golden_cases())
@@ -72,7 +76,7 @@ def test_svd_golden_embed_and_detect(eng, case):
     counts, bits = eng.svd_detect(cuda(g["marked"][None]), 8, want_bits=True)
     bits = bits[0].cpu().numpy()
     assert bits.shape == (N,) and not bits[nblk:].any()
-    assert (bits != g["raw_bits"].reshape(-1)).sum() <= budget(nblk, 5e-3)
+    assert (bits != g["raw_bits"].reshape(-1)).sum() <= budget(nblk, 1e-4)
     assert np.array_equal(counts[0].cpu().numpy(), np.array([bits[i::8].sum() for i in range(8)]))
     out = DeShuffler(key=int(g["key"])).set_shape((8,)).degenerate_counts(counts[0].cpu().numpy(), N)
     assert np.array_equal(out, g["degenerated"])
@@ -97,7 +101,7 @@ def test_svd_1080p_against_oracle_and_payloads(eng):
     assert_pixels_close(marked[0].cpu().numpy(), ref, mask)
     ref_bits = orc.check_frame(ref, orc.DwtDctSvdDecoderOracle())
     _, b2 = eng.svd_detect(cuda(ref[None]), 8, want_bits=True)
-    assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(32400, 5e-3)
+    assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(32400, 1e-4)
     deg = DeShuffler(key=0).set_shape((8,))
     assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), 32400), P8)
 
@@ -169,6 +173,6 @@ def test_svd_random_shapes_and_contents(eng):
             assert_pixels_close(got[k], ref, mask)
             ref_bits = orc.check_frame(ref, orc.DwtDctSvdDecoderOracle())
             _, b2 = eng.svd_detect(cuda(ref[None]), 8, want_bits=True)
-            assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(nblk, 5e-3), (trial, k)
+            assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(nblk, 1e-4), (trial, k)
         c3, b3 = eng.svd_detect(cuda(got), 8, want_bits=True)
         assert np.array_equal(c3.cpu().numpy(), counts.cpu().numpy()) and np.array_equal(b3.cpu().numpy(), bits.cpu().numpy())

@@ -39,6 +39,40 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
             } else if (MODE == 7) {     // byte -> float conversions
 #pragma unroll
                 for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(s[i]));
+            } else if (MODE == 8) {     // byte permute (2 bytes -> two f16 magic halves in one op)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(s[i]) : "v"(m), "v"(a));
+            } else if (MODE == 9) {     // packed f16 add (the -1024 of the magic-number byte->f16 conversion)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(s[i]) : "v"(a));
+            } else if (MODE == 10) {    // mixed-precision fma reading an f16 half directly
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(s[i]) : "v"(m), "v"(a));
+            } else if (MODE == 11) {    // clip + round + pack to u8
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(s[i]) : "v"(m));
+            } else if (MODE == 12) {    // float64 fma (the scalar stage)
+                double *dd = reinterpret_cast<double *>(s);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(dd[i]) : "v"((double)m), "v"((double)a));
+            } else if (MODE == 13) {    // SDWA: integer byte select + convert in one VOP1
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "+v"(s[i]));
+            } else if (MODE == 14) {    // 4-byte integer dot product
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(s[i]) : "v"(m), "v"(a));
+            } else if (MODE == 15) {    // rcp (quarter-rate class)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(s[i]));
+            } else if (MODE == 16) {    // fma with |x| source modifier (VOP3 encoding)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, |%0|, %1, %2" : "+v"(s[i]) : "v"(m), "v"(a));
+            } else if (MODE == 17) {    // fma with a literal constant (v_fmamk_f32)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %1" : "+v"(s[i]) : "v"(a));
+            } else if (MODE == 18) {    // sub
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(s[i]) : "v"(a));
             }
         }
     }
@@ -78,5 +112,16 @@ int main() {
     run<5>("v_pk_add_f32", 2);
     run<6>("v_pk_add_f32 op_sel swap", 2);
     run<7>("v_cvt_f32_ubyte1", 1);
+    run<8>("v_perm_b32", 1);
+    run<9>("v_pk_add_f16", 1);
+    run<10>("v_fma_mix_f32 (f16 src)", 1);
+    run<11>("v_cvt_pk_u8_f32", 1);
+    run<12>("v_fma_f64", 2);
+    run<13>("v_cvt_f32_u32_sdwa BYTE_2", 1);
+    run<14>("v_dot4_u32_u8", 1);
+    run<15>("v_rcp_f32", 1);
+    run<16>("v_fma_f32 |src|", 1);
+    run<17>("v_fmamk_f32 literal", 1);
+    run<18>("v_sub_f32", 1);
     return 0;
 }

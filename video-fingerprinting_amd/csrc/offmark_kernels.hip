@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -47,26 +48,47 @@ using namespace ofmk;
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------
-thread_local char g_err[512] = "";
-int g_self_experiment = 0;   // tools/upper_bound.py only
-int g_onepass = 0;           // ofmk_embed_detect_rgb8: 1 = persistent one-pass kernel (ofmk_set_fused_verify(3))
-int g_onepass_grid = 768;    // workgroups of the persistent kernel (3 per CU; raised to tiles-per-frame if smaller)
-int g_fuse_verify = 1;    // ofmk_embed_detect_rgb8: 1 = fused mark+analyze kernel, 0 = separate kernels
+thread_local char g_err[512] = "";     // the ONLY mutable state of the library: the calling thread's last error text
 
-// Optional per-launch HIP-event timing (bench.py): events are created by ofmk_timing_enable(),
-// attached to the kernel dispatches themselves, and read back by ofmk_timing_collect().
-enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_SVD = 4, KIND_COUNT = 5 };
+// Optional per-launch HIP-event timing (bench.py).  The event pool is an object the CALLER owns
+// (ofmk_timing_create) and passes in ofmk_opts; no library-wide state.
+enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_SVD = 4, KIND_PLANAR = 5, KIND_COUNT = 6 };
 struct TimingRec { hipEvent_t a, b; int kind; };
-TimingRec *g_trec = nullptr;
-int g_trec_cap = 0, g_trec_used = 0;
-unsigned g_trec_mask = 0x1F;     // which kernel kinds get bracketed
+
+}  // namespace
+
+struct ofmk_timing {
+    TimingRec *rec;
+    int cap;
+    std::atomic<int> used;      // launches that took a pair; may exceed cap (then the surplus launches go untimed)
+    unsigned mask;              // which kernel kinds get an event pair
+};
+
+namespace {
+
+// What a launcher needs besides its operands: the stream and the (optional) event pool of this call.
+struct Ctx {
+    hipStream_t s;
+    ofmk_timing *t;
+    unsigned flags;
+};
+Ctx make_ctx(void *stream, const ofmk_opts *o) {
+    Ctx c;
+    c.s = static_cast<hipStream_t>(stream);
+    c.t = o ? o->timing : nullptr;
+    c.flags = o ? o->flags : 0u;
+    return c;
+}
 
 struct ScopedTiming {      // reserves an event pair for the launch that follows (none when timing is off)
     TimingRec *r;
-    ScopedTiming(int kind, hipStream_t) : r(nullptr) {
-        if (g_trec && ((g_trec_mask >> kind) & 1u) && g_trec_used < g_trec_cap) {
-            r = &g_trec[g_trec_used++];
-            r->kind = kind;
+    ScopedTiming(int kind, const Ctx &c) : r(nullptr) {
+        if (c.t && ((c.t->mask >> kind) & 1u)) {
+            const int k = c.t->used.fetch_add(1, std::memory_order_relaxed);
+            if (k < c.t->cap) {
+                r = &c.t->rec[k];
+                r->kind = kind;
+            }
         }
     }
 };
@@ -98,15 +120,13 @@ struct Workspace {
     float *delta;    // [frames][nblk]
     unsigned long long *ysum;    // mean accumulators of the frames analyze() saw
     unsigned long long *ysum2;   // ... of the marked frames (fused mark+verify kernel)
-    unsigned int *ctl;           // one-pass kernel: [0] ticket, [1] error
-    unsigned long long *mean_bits;   // one-pass kernel: acc[frames] then published means [frames]
     int frames;      // chunk capacity
     size_t plane;    // frames * nblk
 };
 
 size_t per_frame_bytes(int H, int W) {
     const size_t nblk = (size_t)(H / 8) * (W / 8);
-    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8 + 16;
+    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8;
 }
 
 int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out) {
@@ -114,7 +134,7 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     if ((uintptr_t)ws % 256) return fail(OFMK_E_ARG, "workspace must be 256-byte aligned%s");
     const size_t per = per_frame_bytes(H, W);
     if (bytes < per + 4096) return fail(OFMK_E_WORKSPACE, "workspace smaller than ofmk_workspace_bytes(1, H, W)%s");
-    size_t cap = (bytes - 4096) / per;    // 4096: room for the 256-byte alignment of the seven carved arrays
+    size_t cap = (bytes - 4096) / per;    // 4096: room for the 256-byte alignment of the carved arrays
     if (want_frames > 0 && (size_t)want_frames < cap) cap = want_frames;
     if (cap > (size_t)kMaxChunk) cap = kMaxChunk;
     const size_t nblk = (size_t)(H / 8) * (W / 8);
@@ -128,10 +148,6 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     out.ysum = reinterpret_cast<unsigned long long *>(p);
     p += align256(cap * kSlots * 8);
     out.ysum2 = reinterpret_cast<unsigned long long *>(p);
-    p += align256(cap * kSlots * 8);
-    out.ctl = reinterpret_cast<unsigned int *>(p);          // 2 uints
-    p += 256;
-    out.mean_bits = reinterpret_cast<unsigned long long *>(p);   // 2 * cap u64
     return OFMK_OK;
 }
 
@@ -161,15 +177,16 @@ bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block 
 }
 
 // zero_counts (optional): [n][L] position sums of these frames, cleared by the kernel for a finalize that follows
-int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, hipStream_t s,
+int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, const Ctx &cx,
                    int32_t *zero_counts = nullptr, int L = 0) {
+    hipStream_t s = cx.s;
     // one fill for both accumulator arrays (they are adjacent): ysum for this pass, ysum2 for a fused mark+verify
     // kernel that may follow -- one dispatch less per step than zeroing ysum2 in front of the mark kernel
     HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws);
     const dim3 grid = block_grid(g, n);
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
-    ScopedTiming timing(KIND_ANALYZE, s);
+    ScopedTiming timing(KIND_ANALYZE, cx);
     if (src == SRC_RGB8) {
         if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
         else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
@@ -181,10 +198,11 @@ int launch_analyze(const void *frames, int src, int n, int H, int W, const Works
     return OFMK_OK;
 }
 
-int launch_finalize(FinArgs a, int n, hipStream_t s) {
+int launch_finalize(FinArgs a, int n, const Ctx &cx) {
+    hipStream_t s = cx.s;
     const int per_wg = kThreads * kFinItems;
     const unsigned gx = (unsigned)((a.N + per_wg - 1) / per_wg);
-    ScopedTiming timing(KIND_FINALIZE, s);
+    ScopedTiming timing(KIND_FINALIZE, cx);
     OFMK_TIMED_LAUNCH(timing, finalize_kernel, dim3(gx, (unsigned)n), dim3(kThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
@@ -193,7 +211,8 @@ int launch_finalize(FinArgs a, int n, hipStream_t s) {
 // Needs the input frames' records in ws.rec / ws.ysum (launch_analyze).  fused = true also leaves the
 // MARKED frames' records in ws.rec and their mean accumulators in ws.ysum2.
 int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
-                     double alpha, const Workspace &ws, bool fused, hipStream_t s, bool ysum2_is_zero = false) {
+                     double alpha, const Workspace &ws, bool fused, const Ctx &cx, bool ysum2_is_zero = false) {
+    hipStream_t s = cx.s;
     if (fused && !ysum2_is_zero) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws);
     const dim3 grid = block_grid(g, n);
@@ -206,55 +225,14 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
     m.N = (int)((long long)H * W / 64);
     m.alpha = alpha;
     {
-        ScopedTiming timing(fused ? KIND_MARK_FUSED : KIND_MARK, s);
-        if (fused && g_self_experiment) {
-            OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<true, true, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
-        } else if (fused) {
+        ScopedTiming timing(fused ? KIND_MARK_FUSED : KIND_MARK, cx);
+        if (fused) {
             if (al) OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<true, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
             else OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<false, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
         } else {
             if (al) OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<true, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
             else OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<false, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
         }
-    }
-    HIP_TRY(hipGetLastError());
-    if (in != out && (H % 8 || W % 8)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
-        HIP_TRY(hipGetLastError());
-    }
-    return OFMK_OK;
-}
-
-// One-pass embed + verify: leaves the marked frames in `out`, their records in ws.rec and their mean
-// accumulators in ws.ysum2 (as the fused mark kernel does), ready for finalize_detect(after_fused_mark).
-int launch_onepass_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
-                        double alpha, const Workspace &ws, hipStream_t s) {
-    HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
-    HIP_TRY(hipMemsetAsync(ws.ctl, 0, 256 + (size_t)2 * ws.frames * sizeof(unsigned long long), s));   // ctl, acc, means
-    const Geom g = make_geom(H, W, ws);
-    MarkArgs m;
-    m.rec = nullptr;
-    m.ysum = nullptr;
-    m.wm = wm;
-    m.wm_row = wm_row;
-    m.N = (int)((long long)H * W / 64);
-    m.alpha = alpha;
-    OnePassCtl ctl;
-    ctl.ticket = ws.ctl;
-    ctl.error = ws.ctl + 1;
-    ctl.acc = ws.mean_bits;
-    ctl.mean_bits = ws.mean_bits + ws.frames;
-    ctl.tiles_per_frame = (g.nblk + kThreads - 1) / kThreads;
-    ctl.total_tiles = ctl.tiles_per_frame * n;
-    // A workgroup holds ONE tile while it waits for its frame, so a frame only completes if at least
-    // tiles_per_frame workgroups run at once (the caller checked that against the residency limit).
-    int grid = g_onepass_grid < ctl.tiles_per_frame ? ctl.tiles_per_frame : g_onepass_grid;
-    if (grid > ctl.total_tiles) grid = ctl.total_tiles;
-    const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
-    {
-        ScopedTiming timing(KIND_MARK_FUSED, s);
-        if (al) OFMK_TIMED_LAUNCH(timing, embed_onepass_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2, ctl);
-        else OFMK_TIMED_LAUNCH(timing, embed_onepass_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2, ctl);
     }
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
@@ -278,7 +256,7 @@ FinArgs fin_base(const Workspace &ws, int H, int W, double alpha) {
 }
 
 int finalize_detect(int f0, int cf, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
-                    const Workspace &ws, bool after_fused_mark, hipStream_t s) {
+                    const Workspace &ws, bool after_fused_mark, const Ctx &s) {
     FinArgs a = fin_base(ws, H, W, alpha);
     if (after_fused_mark) a.ysum = ws.ysum2;
     a.L = L;
@@ -290,7 +268,7 @@ int finalize_detect(int f0, int cf, int H, int W, int L, double alpha, int32_t *
 // analyze + mark for frames [f0, f0+cf); verify = also leave the marked frames' records in the
 // workspace (fused kernel), ready for finalize_detect(after_fused_mark = true)
 int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W, const uint8_t *wm,
-                const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, hipStream_t s,
+                const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, const Ctx &s,
                 int32_t *zero_counts = nullptr, int L = 0) {
     const size_t fs = (size_t)H * W * 3;
     const size_t esz = src == SRC_RGB8 ? 1 : 4;
@@ -309,13 +287,13 @@ int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W
     a.delta = ws.delta;
     if ((rc = launch_finalize(a, cf, s))) return rc;
     const Geom g = make_geom(H, W, ws);
-    hipLaunchKernelGGL(mark_yuv32f_kernel, block_grid(g, cf), dim3(kThreads), 0, s, reinterpret_cast<float *>(pout), g, ws.delta);
+    hipLaunchKernelGGL(mark_yuv32f_kernel, block_grid(g, cf), dim3(kThreads), 0, s.s, reinterpret_cast<float *>(pout), g, ws.delta);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
 
 int detect_chunk(const void *in, int src, int f0, int cf, int H, int W, int L, double alpha, int32_t *counts,
-                 uint8_t *bits, const Workspace &ws, hipStream_t s) {
+                 uint8_t *bits, const Workspace &ws, const Ctx &s) {
     const size_t fs = (size_t)H * W * 3;
     const size_t esz = src == SRC_RGB8 ? 1 : 4;
     const char *pin = static_cast<const char *>(in) + (size_t)f0 * fs * esz;
@@ -325,7 +303,8 @@ int detect_chunk(const void *in, int src, int f0, int cf, int H, int W, int L, d
 }
 
 // ---- DwtDctSvd codec ---------------------------------------------------------------------------
-int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mode, SvdArgs a, hipStream_t s) {
+int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mode, SvdArgs a, const Ctx &cx) {
+    hipStream_t s = cx.s;
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
@@ -340,7 +319,7 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
         if (b.counts) b.counts += (size_t)f0 * a.L;
         if (b.bits) b.bits += (size_t)f0 * a.N;
         const dim3 grid = block_grid(g, cf);
-        ScopedTiming timing(KIND_SVD, s);
+        ScopedTiming timing(KIND_SVD, cx);
 #define OFMK_SVD_LAUNCH(AL, MD) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
         if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT); else OFMK_SVD_LAUNCH(false, SVD_DETECT); }
         else if (mode == SVD_EMBED) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED); else OFMK_SVD_LAUNCH(false, SVD_EMBED); }
@@ -384,47 +363,31 @@ size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W) {
     return per_frame_bytes(H, W) * (size_t)frames_in_flight + 4096;
 }
 
-void ofmk_set_fused_verify(int on) {
-    g_fuse_verify = on ? 1 : 0;
-    g_self_experiment = on == 2 ? 1 : 0;
-    g_onepass = on == 3 ? 1 : 0;
-}
-
-void ofmk_set_onepass_grid(int workgroups) { g_onepass_grid = workgroups > 0 ? workgroups : 768; }
-
-int ofmk_onepass_error(void *workspace, size_t workspace_bytes, int H, int W, int chunk_frames, unsigned int *host_flag) {
-    Workspace ws;
-    int rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(host_flag, ws.ctl + 1, sizeof(unsigned int), hipMemcpyDeviceToHost));
-    return OFMK_OK;
-}
-
 int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                     const int32_t *wm_row, double alpha, int chunk_frames, void *workspace, size_t workspace_bytes,
-                    void *stream) {
+                    void *stream, const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ctx cx = make_ctx(stream, opts);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
+        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, cx))) return rc;
     }
     return OFMK_OK;
 }
 
 int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
-                     int chunk_frames, void *workspace, size_t workspace_bytes, void *stream) {
+                     int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ctx cx = make_ctx(stream, opts);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {      // counts are cleared by each chunk's analyze kernel
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = detect_chunk(in, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+        if ((rc = detect_chunk(in, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, cx))) return rc;
     }
     return OFMK_OK;
 }
@@ -440,45 +403,38 @@ int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double 
     if (L < 1) return fail(OFMK_E_ARG, "payload length L must be >= 1%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemsetAsync(soft, 0, (size_t)n * L * sizeof(long long), s));
+    const Ctx cx = make_ctx(stream, nullptr);
+    HIP_TRY(hipMemsetAsync(soft, 0, (size_t)n * L * sizeof(long long), cx.s));
     const size_t fs = (size_t)H * W * 3;
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = launch_analyze(in + (size_t)f0 * fs, SRC_RGB8, cf, H, W, ws, s))) return rc;
+        if ((rc = launch_analyze(in + (size_t)f0 * fs, SRC_RGB8, cf, H, W, ws, cx))) return rc;
         FinArgs a = fin_base(ws, H, W, alpha);
         a.L = L;
         a.soft = soft + (size_t)f0 * L;
-        if ((rc = launch_finalize(a, cf, s))) return rc;
+        if ((rc = launch_finalize(a, cf, cx))) return rc;
     }
     return OFMK_OK;
 }
 
 int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                            const int32_t *wm_row, double alpha, int L, int32_t *counts, uint8_t *bits,
-                           int chunk_frames, void *workspace, size_t workspace_bytes, void *stream) {
+                           int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                           const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool onepass = g_onepass && (((H / 8) * (W / 8) + kThreads - 1) / kThreads) <= 512;
-    if (counts && onepass) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));   // else: analyze clears them
+    const Ctx cx = make_ctx(stream, opts);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        // one-pass needs every tile of a frame in flight at once: 2 workgroups per CU are always resident
-        // (150 VGPRs -> 3), so frames of up to 512 tiles (131 072 blocks, e.g. 4K) qualify
-        if (onepass) {
-            const size_t fo = (size_t)f0 * H * W * 3;
-            if ((rc = launch_onepass_rgb8(in + fo, out + fo, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, s))) return rc;
-            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
-        } else if (g_fuse_verify) {
-            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, s, counts, L))) return rc;
-            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, s))) return rc;
+        if (!(cx.flags & OFMK_F_SEPARATE_DETECT)) {
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, cx, counts, L))) return rc;
+            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, cx))) return rc;
         } else {
-            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
-            if ((rc = detect_chunk(out, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, cx))) return rc;
+            if ((rc = detect_chunk(out, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, cx))) return rc;
         }
     }
     return OFMK_OK;
@@ -490,10 +446,10 @@ int ofmk_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ctx cx = make_ctx(stream, nullptr);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(yuv, yuv, SRC_YUV32F, f0, cf, H, W, wm, wm_row, alpha, ws, false, s))) return rc;
+        if ((rc = embed_chunk(yuv, yuv, SRC_YUV32F, f0, cf, H, W, wm, wm_row, alpha, ws, false, cx))) return rc;
     }
     return OFMK_OK;
 }
@@ -504,10 +460,10 @@ int ofmk_decode_yuv32f(const float *yuv, int n, int H, int W, int L, double alph
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ctx cx = make_ctx(stream, nullptr);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = detect_chunk(yuv, SRC_YUV32F, f0, cf, H, W, L, alpha, counts, bits, ws, s))) return rc;
+        if ((rc = detect_chunk(yuv, SRC_YUV32F, f0, cf, H, W, L, alpha, counts, bits, ws, cx))) return rc;
     }
     return OFMK_OK;
 }
@@ -521,8 +477,8 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
     if (c21_post && !wm) return fail(OFMK_E_ARG, "c21_post requested without a watermark%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, 1, ws))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if ((rc = launch_analyze(frame, src_is_yuv32f ? SRC_YUV32F : SRC_RGB8, 1, H, W, ws, s))) return rc;
+    const Ctx cx = make_ctx(stream, nullptr);
+    if ((rc = launch_analyze(frame, src_is_yuv32f ? SRC_YUV32F : SRC_RGB8, 1, H, W, ws, cx))) return rc;
     FinArgs a = fin_base(ws, H, W, alpha);
     a.wm = wm;
     a.y_dc = y_dc;
@@ -531,55 +487,55 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
     a.step = step;
     a.c21_pre = c21_pre;
     a.c21_post = wm ? c21_post : nullptr;
-    return launch_finalize(a, 1, s);
+    return launch_finalize(a, 1, cx);
 }
 
 int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W, void *workspace, size_t workspace_bytes,
-                            void *stream) {
+                            void *stream, const ofmk_opts *opts) {
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!in) return fail(OFMK_E_ARG, "null frame pointer%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, n, ws))) return rc;
     if (ws.frames < n) return fail(OFMK_E_WORKSPACE, "stage call needs workspace for all n frames%s");
-    return launch_analyze(in, SRC_RGB8, n, H, W, ws, static_cast<hipStream_t>(stream));
+    return launch_analyze(in, SRC_RGB8, n, H, W, ws, make_ctx(stream, opts));
 }
 
 int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, double alpha,
-                         int fused, void *workspace, size_t workspace_bytes, void *stream) {
+                         int fused, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, 1);
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, n, ws))) return rc;
     if (ws.frames < n) return fail(OFMK_E_WORKSPACE, "stage call needs workspace for all n frames%s");
-    return launch_mark_rgb8(in, out, n, H, W, wm, nullptr, alpha, ws, fused != 0, static_cast<hipStream_t>(stream));
+    return launch_mark_rgb8(in, out, n, H, W, wm, nullptr, alpha, ws, fused != 0, make_ctx(stream, opts));
 }
 
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
-                        const int32_t *wm_row, double scale, void *stream) {
+                        const int32_t *wm_row, double scale, void *stream, const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
-    return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED, a, static_cast<hipStream_t>(stream));
+    return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double scale, int32_t *counts, uint8_t *bits,
-                         void *stream) {
+                         void *stream, const ofmk_opts *opts) {
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
     if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     a.counts = counts; a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = L; a.scale = (float)scale;
-    return launch_svd_rgb8(in, nullptr, n, H, W, SVD_DETECT, a, static_cast<hipStream_t>(stream));
+    return launch_svd_rgb8(in, nullptr, n, H, W, SVD_DETECT, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                                const int32_t *wm_row, double scale, int L, int32_t *counts, uint8_t *bits,
-                               void *stream) {
+                               void *stream, const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
@@ -588,7 +544,7 @@ int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, in
     memset(&a, 0, sizeof(a));
     a.wm = wm; a.wm_row = wm_row; a.counts = counts; a.bits = bits;
     a.N = (int)((long long)H * W / 64); a.L = L; a.scale = (float)scale;
-    return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, a, static_cast<hipStream_t>(stream));
+    return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
@@ -635,49 +591,71 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
     return OFMK_OK;
 }
 
-int ofmk_timing_enable(int max_launches, unsigned kind_mask) {
-    if (g_trec) return fail(OFMK_E_ARG, "timing already enabled%s");
-    g_trec_mask = kind_mask ? kind_mask : 0x1F;
+// ---- timing objects (caller-owned; see the header) ------------------------------------------------
+int ofmk_timing_create(int max_launches, unsigned kind_mask, ofmk_timing **out) {
+    if (!out) return fail(OFMK_E_ARG, "null output%s");
+    *out = nullptr;
     if (max_launches < 1) return fail(OFMK_E_ARG, "max_launches must be positive%s");
-    g_trec = new TimingRec[max_launches];
+    ofmk_timing *t = new ofmk_timing;
+    t->rec = new TimingRec[max_launches];
+    t->cap = 0;
+    t->used.store(0);
+    t->mask = kind_mask ? kind_mask : 0xFFFFFFFFu;
     for (int i = 0; i < max_launches; ++i) {
-        HIP_TRY(hipEventCreate(&g_trec[i].a));
-        HIP_TRY(hipEventCreate(&g_trec[i].b));
+        hipError_t e = hipEventCreate(&t->rec[i].a);
+        if (e == hipSuccess) e = hipEventCreate(&t->rec[i].b);
+        if (e != hipSuccess) {
+            ofmk_timing_destroy(t);
+            return fail(OFMK_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+        t->cap = i + 1;
     }
-    g_trec_cap = max_launches;
-    g_trec_used = 0;
+    *out = t;
     return OFMK_OK;
 }
 
-int ofmk_timing_collect(double *ms_by_kind, int *launches_by_kind) {
-    if (!g_trec) return fail(OFMK_E_ARG, "timing is not enabled%s");
-    if (!ms_by_kind || !launches_by_kind) return fail(OFMK_E_ARG, "null output%s");
+int ofmk_timing_collect(ofmk_timing *t, double *ms_by_kind, int *launches_by_kind) {
+    if (!t || !ms_by_kind || !launches_by_kind) return fail(OFMK_E_ARG, "null pointer%s");
     for (int k = 0; k < KIND_COUNT; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
-    for (int i = 0; i < g_trec_used; ++i) {
-        HIP_TRY(hipEventSynchronize(g_trec[i].b));
+    const int taken = t->used.load();
+    const int used = taken < t->cap ? taken : t->cap;
+    for (int i = 0; i < used; ++i) {
+        HIP_TRY(hipEventSynchronize(t->rec[i].b));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, g_trec[i].a, g_trec[i].b));
-        ms_by_kind[g_trec[i].kind] += ms;
-        launches_by_kind[g_trec[i].kind] += 1;
+        HIP_TRY(hipEventElapsedTime(&ms, t->rec[i].a, t->rec[i].b));
+        ms_by_kind[t->rec[i].kind] += ms;
+        launches_by_kind[t->rec[i].kind] += 1;
     }
-    g_trec_used = 0;
+    t->used.store(0);
     return OFMK_OK;
 }
 
-void ofmk_timing_disable(void) {
-    if (!g_trec) return;
-    for (int i = 0; i < g_trec_cap; ++i) { (void)hipEventDestroy(g_trec[i].a); (void)hipEventDestroy(g_trec[i].b); }
-    delete[] g_trec;
-    g_trec = nullptr;
-    g_trec_cap = g_trec_used = 0;
+void ofmk_timing_destroy(ofmk_timing *t) {
+    if (!t) return;
+    for (int i = 0; i < t->cap; ++i) { (void)hipEventDestroy(t->rec[i].a); (void)hipEventDestroy(t->rec[i].b); }
+    delete[] t->rec;
+    delete t;
 }
 
+// ---- streaming probes: the device's achievable HBM rates, measured in the same run as the kernels ----
 int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream) {
     if (!src || !dst || bytes % 16 || (uintptr_t)src % 16 || (uintptr_t)dst % 16)
         return fail(OFMK_E_ARG, "copy needs 16-byte aligned pointers and size%s");
     const size_t n16 = bytes / 16;
-    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + kThreads * 4 - 1) / (kThreads * 4))), dim3(kThreads), 0,
+    if (n16 == 0) return OFMK_OK;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)((n16 + kCopyPerWg - 1) / kCopyPerWg)), dim3(kThreads), 0,
                        static_cast<hipStream_t>(stream), static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int ofmk_hbm_read(const void *src, size_t bytes, void *sink, void *stream) {
+    if (!src || !sink || bytes % 16 || (uintptr_t)src % 16 || (uintptr_t)sink % 4)
+        return fail(OFMK_E_ARG, "read probe needs a 16-byte aligned source and size, and a 4-byte sink%s");
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return OFMK_OK;
+    hipLaunchKernelGGL(read16_kernel, dim3((unsigned)((n16 + kReadPerWg - 1) / kReadPerWg)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint4 *>(src), n16, static_cast<uint32_t *>(sink));
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }

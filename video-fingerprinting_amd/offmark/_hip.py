@@ -12,15 +12,48 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liboffmark_hip.so")
 
-#: every symbol include/offmark_hip.h declares
-SYMBOLS = (
-    "ofmk_version", "ofmk_last_error", "ofmk_workspace_bytes", "ofmk_embed_rgb8", "ofmk_detect_rgb8",
-    "ofmk_embed_detect_rgb8", "ofmk_encode_yuv32f", "ofmk_decode_yuv32f", "ofmk_debug_planes",
-    "ofmk_stage_analyze_rgb8", "ofmk_stage_mark_rgb8", "ofmk_hbm_copy", "ofmk_set_fused_verify",
-    "ofmk_timing_enable", "ofmk_timing_collect", "ofmk_timing_disable", "ofmk_payloads_from_counts",
-    "ofmk_svd_embed_rgb8", "ofmk_svd_detect_rgb8", "ofmk_svd_embed_detect_rgb8", "ofmk_svd_encode_yuv32f",
-    "ofmk_svd_decode_yuv32f", "ofmk_set_onepass_grid", "ofmk_onepass_error", "ofmk_detect_soft_rgb8",
-)
+ABI_VERSION = 2
+
+
+class Opts(C.Structure):
+    """ofmk_opts: per-call options (flags, optional timing object).  None / NULL = defaults."""
+    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_uint32), ("timing", C.c_void_p)]
+
+
+F_SEPARATE_DETECT = 1
+TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar")
+
+_vp, _i32, _f64, _sz, _u32 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint
+_op = C.POINTER(Opts)
+
+#: every symbol include/offmark_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "ofmk_version": (_i32, []),
+    "ofmk_last_error": (C.c_char_p, []),
+    "ofmk_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "ofmk_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_detect_soft_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _sz, _vp]),
+    "ofmk_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _i32, _vp, _sz,
+                                      _vp, _op]),
+    "ofmk_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp]),
+    "ofmk_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "ofmk_debug_planes": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ofmk_stage_analyze_rgb8": (_i32, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_stage_mark_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_svd_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _vp, _op]),
+    "ofmk_svd_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _op]),
+    "ofmk_svd_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _vp, _op]),
+    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _vp]),
+    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp]),
+    "ofmk_payloads_from_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ofmk_hbm_copy": (_i32, [_vp, _vp, _sz, _vp]),
+    "ofmk_hbm_read": (_i32, [_vp, _sz, _vp, _vp]),
+    "ofmk_timing_create": (_i32, [_i32, _u32, C.POINTER(_vp)]),
+    "ofmk_timing_collect": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i32)]),
+    "ofmk_timing_destroy": (None, [_vp]),
+}
+SYMBOLS = tuple(SIGNATURES)
 
 
 class HipLibraryMissing(RuntimeError):
@@ -48,52 +81,47 @@ def load():
             f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  offmark's DCT codec has no CPU fallback.")
     lib = C.CDLL(_LIB_PATH)
-    vp, i32, f64, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
-    lib.ofmk_version.restype = i32
-    lib.ofmk_last_error.restype = C.c_char_p
-    lib.ofmk_workspace_bytes.restype = sz
-    lib.ofmk_workspace_bytes.argtypes = [i32, i32, i32]
-    lib.ofmk_embed_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f64, i32, vp, sz, vp]
-    lib.ofmk_detect_rgb8.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, sz, vp]
-    lib.ofmk_embed_detect_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f64, i32, vp, vp, i32, vp, sz, vp]
-    lib.ofmk_encode_yuv32f.argtypes = [vp, i32, i32, i32, vp, i32, vp, f64, i32, vp, sz, vp]
-    lib.ofmk_decode_yuv32f.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, i32, vp, sz, vp]
-    lib.ofmk_debug_planes.argtypes = [vp, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
-    lib.ofmk_stage_analyze_rgb8.argtypes = [vp, i32, i32, i32, vp, sz, vp]
-    lib.ofmk_stage_mark_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, f64, i32, vp, sz, vp]
-    lib.ofmk_hbm_copy.argtypes = [vp, vp, sz, vp]
-    lib.ofmk_set_fused_verify.argtypes = [i32]
-    lib.ofmk_set_fused_verify.restype = None
-    lib.ofmk_payloads_from_counts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-    lib.ofmk_payloads_from_counts.restype = i32
-    lib.ofmk_svd_embed_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f64, vp]
-    lib.ofmk_svd_detect_rgb8.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, vp]
-    lib.ofmk_svd_embed_detect_rgb8.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, f64, i32, vp, vp, vp]
-    lib.ofmk_svd_encode_yuv32f.argtypes = [vp, i32, i32, i32, vp, i32, vp, f64, vp]
-    lib.ofmk_svd_decode_yuv32f.argtypes = [vp, i32, i32, i32, f64, vp, vp]
-    for name in ("ofmk_svd_embed_rgb8", "ofmk_svd_detect_rgb8", "ofmk_svd_embed_detect_rgb8",
-                 "ofmk_svd_encode_yuv32f", "ofmk_svd_decode_yuv32f"):
-        getattr(lib, name).restype = i32
-    lib.ofmk_detect_soft_rgb8.argtypes = [vp, i32, i32, i32, i32, f64, vp, i32, vp, sz, vp]
-    lib.ofmk_detect_soft_rgb8.restype = i32
-    lib.ofmk_set_onepass_grid.argtypes = [i32]
-    lib.ofmk_set_onepass_grid.restype = None
-    lib.ofmk_onepass_error.argtypes = [vp, sz, i32, i32, i32, C.POINTER(C.c_uint)]
-    lib.ofmk_onepass_error.restype = i32
-    lib.ofmk_timing_enable.argtypes = [i32, C.c_uint]
-    lib.ofmk_timing_enable.restype = i32
-    lib.ofmk_timing_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    lib.ofmk_timing_collect.restype = i32
-    lib.ofmk_timing_disable.argtypes = []
-    lib.ofmk_timing_disable.restype = None
-    for name in ("ofmk_embed_rgb8", "ofmk_detect_rgb8", "ofmk_embed_detect_rgb8", "ofmk_encode_yuv32f",
-                 "ofmk_decode_yuv32f", "ofmk_debug_planes", "ofmk_stage_analyze_rgb8", "ofmk_stage_mark_rgb8",
-                 "ofmk_hbm_copy"):
-        getattr(lib, name).restype = i32
-    if lib.ofmk_version() != 1:
-        raise HipError(f"ABI version mismatch: library reports {lib.ofmk_version()}, binding expects 1")
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.ofmk_version() != ABI_VERSION:
+        raise HipError(f"ABI version mismatch: library reports {lib.ofmk_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+class Timing:
+    """Caller-owned event pool (ofmk_timing_create): pass `.opts()` to the calls whose kernels should be timed."""
+
+    def __init__(self, max_launches: int, kind_mask: int = 0):
+        self.lib = load()
+        self.handle = _vp()
+        check(self.lib.ofmk_timing_create(int(max_launches), int(kind_mask), C.byref(self.handle)))
+
+    def opts(self, flags: int = 0) -> Opts:
+        return Opts(flags, 0, self.handle)
+
+    def collect(self) -> dict:
+        ms = (_f64 * len(TIMING_KINDS))()
+        cnt = (_i32 * len(TIMING_KINDS))()
+        check(self.lib.ofmk_timing_collect(self.handle, ms, cnt))
+        return {k: dict(ms_total=ms[i], launches=cnt[i]) for i, k in enumerate(TIMING_KINDS)}
+
+    def close(self):
+        if self.handle:
+            self.lib.ofmk_timing_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def opts_ref(o):
+    """ctypes argument for an optional Opts."""
+    return None if o is None else C.byref(o)
 
 
 def check(rc: int) -> None:

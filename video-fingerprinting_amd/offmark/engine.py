@@ -26,7 +26,10 @@ def default_chunk_frames(H: int, W: int, bytes_per_sample: int = 1) -> int:
 class DctEngine:
     """Enqueue embed / detect for batches of interleaved u8 frames [n, H, W, 3] on one GPU."""
 
-    def __init__(self, device=None, chunk_frames: int | None = None):
+    def __init__(self, device=None, chunk_frames: int | None = None, opts=None):
+        """opts: an _hip.Opts applied to every batch call of this engine (flags, timing object); engines share
+        no state, so two engines on two streams may be driven from two threads."""
+        self.opts = opts
         self.torch = _hip.require_gpu()
         self.lib = _hip.load()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device()) if device is None \
@@ -101,7 +104,7 @@ class DctEngine:
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
                                             _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
-                                            _hip.current_stream()))
+                                            _hip.current_stream(), _hip.opts_ref(self.opts)))
         return out
 
     def detect(self, frames, L, alpha=20, want_bits=False):
@@ -114,7 +117,8 @@ class DctEngine:
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_detect_rgb8(frames.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
-                                             _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
+                                             _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(),
+                                             _hip.opts_ref(self.opts)))
         return counts, bits
 
     def detect_soft(self, frames, L, alpha=20):
@@ -144,7 +148,7 @@ class DctEngine:
         _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                    wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
                                                    counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
-                                                   _hip.current_stream()))
+                                                   _hip.current_stream(), _hip.opts_ref(self.opts)))
         return out, counts, bits
 
     def payloads(self, counts, n_bits: int, perm, out=None):
@@ -192,7 +196,8 @@ class DctEngine:
         if out is None:
             out = t.empty_like(frames)
         _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
-                                                _hip.ptr(rows), float(scale), _hip.current_stream()))
+                                                _hip.ptr(rows), float(scale), _hip.current_stream(),
+                                                _hip.opts_ref(self.opts)))
         return out
 
     def svd_detect(self, frames, L, scale=15, want_bits=False):
@@ -201,7 +206,7 @@ class DctEngine:
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), float(scale), counts.data_ptr(),
-                                                 _hip.ptr(bits), _hip.current_stream()))
+                                                 _hip.ptr(bits), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return counts, bits
 
     def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False):
@@ -215,7 +220,8 @@ class DctEngine:
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                        wm.shape[0], _hip.ptr(rows), float(scale), int(L),
-                                                       counts.data_ptr(), _hip.ptr(bits), _hip.current_stream()))
+                                                       counts.data_ptr(), _hip.ptr(bits), _hip.current_stream(),
+                                                       _hip.opts_ref(self.opts)))
         return out, counts, bits
 
     def svd_encode_yuv(self, yuv, wm, scale=15):
