@@ -203,7 +203,9 @@ int launch_finalize(FinArgs a, int n, const Ctx &cx) {
     const int per_wg = kThreads * kFinItems;
     const unsigned gx = (unsigned)((a.N + per_wg - 1) / per_wg);
     ScopedTiming timing(KIND_FINALIZE, cx);
-    OFMK_TIMED_LAUNCH(timing, finalize_kernel, dim3(gx, (unsigned)n), dim3(kThreads), 0, s, a);
+    const bool full = a.delta || a.soft || a.y_dc || a.lum || a.tex || a.step || a.c21_pre || a.c21_post;
+    if (full) OFMK_TIMED_LAUNCH(timing, finalize_kernel<true>, dim3(gx, (unsigned)n), dim3(kThreads), 0, s, a);
+    else OFMK_TIMED_LAUNCH(timing, finalize_kernel<false>, dim3(gx, (unsigned)n), dim3(kThreads), 0, s, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
