@@ -109,21 +109,53 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
 /* ---- DwtDctSvd codec (what tests/mark.py and tests/detect.py construct) -----------------------
  * src/offmark/embed/dwt_dct_svd_encoder.py:19-45 (Haar LL of channel 1 -> 4x4 blocks -> DCT -> SVD ->
  * s[0] = (s[0] // scale + 0.25 + 0.5*bit) * scale -> back) and
- * src/offmark/extract/dwt_dct_svd_decoder.py:12-37 (bit = (s[0] % scale) > scale/2), for the
- * reference's default scales=[0, scale, 0], blk=4.  Same frame/watermark/counts/bits conventions as
- * the DCT entry points; no workspace (this codec has no frame-global dependency: one pass).     */
+ * src/offmark/extract/dwt_dct_svd_decoder.py:12-37 (bit = (s[0] % scale) > scale/2), blk = 4.
+ *   scales   HOST array of 3 doubles, one per YUV channel as in DwtDctSvdEncoder(scales=[0,15,0])
+ *            (dwt_dct_svd_encoder.py:6,19-26): every channel with a positive scale is marked with the same
+ *            watermark; the read-out is channel 1's (dwt_dct_svd_decoder.py:24 returns wm_bits[1]), so
+ *            detection with scales[1] <= 0 yields zeros, as in the reference.
+ * Same frame/watermark/counts/bits conventions as the DCT entry points; no workspace (this codec has no
+ * frame-global dependency: one pass).                                                            */
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
-                        const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream,
+                        const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, void *stream,
                         const ofmk_opts *opts);
-int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double scale,
+int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales,
                          int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
-                               const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale,
+                               const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales,
                                int L, int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
-/* plugin level, float32 YUV [n][H][W][3] (n <= 65535): encode mutates channel 1; decode fills bits */
+/* plugin level, float32 YUV [n][H][W][3] (n <= 65535): encode mutates the marked channels; decode fills bits */
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W,
-                           const uint8_t *wm, int n_wm, const int32_t *wm_row, double scale, void *stream);
-int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, double scale, uint8_t *bits, void *stream);
+                           const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, void *stream);
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream);
+
+/* ---- planar 8-bit YUV 4:2:0 on either side of the DCT codec ------------------------------
+ * The reference moves rgb24 over pipes and has ffmpeg convert to yuv420p on the way out
+ * (src/offmark/video/frame_reader.py:42-64, src/offmark/video/frame_writer.py:33-34).  These entry points take and
+ * produce the 4:2:0 planes themselves, so a decoder's output stays on the device and HBM / PCIe carry 1.5 instead
+ * of 3 bytes per pixel each way.  The result is, bit for bit,
+ *     ofmk_yuv420_to_rgb8 -> ofmk_embed_rgb8 / ofmk_detect_rgb8 -> ofmk_rgb8_to_yuv420
+ * with the conversions fused into the kernels' loads and stores.  The conversion is BUILD-DEFINED (swscale is not
+ * available here and its rounding is not claimed): BT.601 studio swing in float32 fused multiply-adds, clip to
+ * [0,255], round half to even; chroma is replicated over its 2x2 pixels on the way in and is the conversion of the
+ * 2x2 mean RGB on the way out (csrc/planar_kernels.hiph, restated in oracle/offmark_oracle.py).
+ *   layout  OFMK_YUV_I420: per frame [Y: H*W][U: H/2*W/2][V: H/2*W/2];  OFMK_YUV_NV12: [Y: H*W][UV interleaved: H/2*W]
+ *           frames are consecutive, 1.5*H*W bytes each; H and W must be multiples of 8, buffers 8-byte aligned
+ *   ofmk_embed_detect_yuv420's counts/bits are those of a reader of the WRITTEN planes (== ofmk_detect_yuv420(out)). */
+#define OFMK_YUV_I420 0
+#define OFMK_YUV_NV12 1
+int ofmk_embed_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W,
+                      const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
+                      int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
+int ofmk_detect_yuv420(const uint8_t *in, int layout, int n, int H, int W, int L, double alpha,
+                       int32_t *counts, uint8_t *bits,
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
+int ofmk_embed_detect_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W,
+                             const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
+                             int L, int32_t *counts, uint8_t *bits,
+                             int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
+int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int H, int W, void *stream);
+int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int H, int W, void *stream);
 
 /* ---- DeShuffler.degenerate's epilogue for a batch, on the device ---------------------------
  * src/offmark/degenerator/de_shuffler.py:17-22: mean of bits[i::L] (from `counts`), undo the key

@@ -249,6 +249,66 @@ def yuv2bgr_f32(img: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# (f)-3  planar 8-bit YUV 4:2:0 <-> rgb24: BUILD-DEFINED conversion (csrc/planar_kernels.hiph restated)
+# --------------------------------------------------------------------------------------
+# The reference has ffmpeg do this (frame_reader.py:42-64 asks for rgb24, frame_writer.py:33-34 writes yuv420p);
+# swscale is not available, so the build states its own conversion and this is its CPU restatement, operation for
+# operation: BT.601 studio swing, float32 fused multiply-adds in the order written, clip to [0, 255], round half
+# to even; chroma replicated over its 2x2 pixels on the way in, conversion of the 2x2 mean RGB on the way out.
+_CY, _CY0, _CRV, _CGU, _CGV, _CBU = F32(1.164383), F32(-18.63013), F32(1.596027), F32(-0.391762), F32(-0.812968), F32(2.017232)
+_EYR, _EYG, _EYB = F32(0.256788), F32(0.504129), F32(0.097906)
+_EUR, _EUG, _EUB = F32(-0.148223), F32(-0.290993), F32(0.439216)
+_EVR, _EVG, _EVB = F32(0.439216), F32(-0.367788), F32(-0.071427)
+
+
+def _round_u8(x):
+    return np.around(np.clip(x, 0, 255)).astype(np.uint8)
+
+
+def yuv420_to_rgb(y: np.ndarray, u: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """y (H, W), u, v (H/2, W/2) uint8 -> rgb24 (H, W, 3) uint8 (channel 0 = R)."""
+    yc = _fma32(y.astype(F32), _CY, np.full(y.shape, _CY0, F32))
+    d = np.repeat(np.repeat(u.astype(F32) - F32(128), 2, 0), 2, 1)
+    e = np.repeat(np.repeat(v.astype(F32) - F32(128), 2, 0), 2, 1)
+    r = _fma32(e, _CRV, yc)
+    g = _fma32(d, _CGU, _fma32(e, _CGV, yc))
+    b = _fma32(d, _CBU, yc)
+    return np.stack([_round_u8(r), _round_u8(g), _round_u8(b)], -1)
+
+
+def rgb_to_yuv420(rgb: np.ndarray):
+    """rgb24 (H, W, 3) uint8, H and W even -> (y (H, W), u (H/2, W/2), v (H/2, W/2)) uint8."""
+    c = rgb.astype(F32)
+    r, g, b = c[..., 0], c[..., 1], c[..., 2]
+    y = _fma32(r, _EYR, _fma32(g, _EYG, _fma32(b, _EYB, np.full(r.shape, 16, F32))))
+
+    def cell_mean(p):                       # sums of four bytes are exact in float32; x 0.25 is exact
+        return (((p[0::2, 0::2] + p[0::2, 1::2]) + p[1::2, 0::2]) + p[1::2, 1::2]) * F32(0.25)
+
+    rm, gm, bm = cell_mean(r), cell_mean(g), cell_mean(b)
+    k128 = np.full(rm.shape, 128, F32)
+    u = _fma32(rm, _EUR, _fma32(gm, _EUG, _fma32(bm, _EUB, k128)))
+    v = _fma32(rm, _EVR, _fma32(gm, _EVG, _fma32(bm, _EVB, k128)))
+    return _round_u8(y), _round_u8(u), _round_u8(v)
+
+
+def pack_yuv420(y, u, v, layout: str = "i420") -> np.ndarray:
+    """One frame's planes as the flat byte layout of the C ABI: I420 = Y | U | V, NV12 = Y | UV interleaved."""
+    if layout == "i420":
+        return np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])
+    return np.concatenate([y.reshape(-1), np.stack([u, v], -1).reshape(-1)])
+
+
+def unpack_yuv420(buf: np.ndarray, H: int, W: int, layout: str = "i420"):
+    y = buf[: H * W].reshape(H, W)
+    if layout == "i420":
+        q = H * W // 4
+        return y, buf[H * W: H * W + q].reshape(H // 2, W // 2), buf[H * W + q: H * W + 2 * q].reshape(H // 2, W // 2)
+    uv = buf[H * W:].reshape(H // 2, W // 2, 2)
+    return y, uv[..., 0], uv[..., 1]
+
+
+# --------------------------------------------------------------------------------------
 # Block helpers
 # --------------------------------------------------------------------------------------
 
@@ -568,6 +628,7 @@ class DwtDctSvdEncoderOracle:
     def __init__(self, key=None, scales=(0, 15, 0), blk=4, form: str = "vec"):
         self.key, self.scales, self.blk, self.form = key, list(scales), blk, form
         self.debug: dict = {}
+        self.debug_ch: dict = {}              # per marked channel: s0, s0_new, gap (vec form)
 
     def read_wm(self, wm):
         self.wm = wm[0]
@@ -578,6 +639,7 @@ class DwtDctSvdEncoderOracle:
 
     def encode(self, yuv):
         row, col, _ = yuv.shape
+        self.debug_ch = {}
         for channel in range(3):
             scale = self.scales[channel]
             if scale <= 0:
@@ -602,7 +664,8 @@ class DwtDctSvdEncoderOracle:
                 s[..., 0] = ((s[..., 0] // scale + 0.25 + 0.5 * bits) * scale).astype(F32)
                 new = idct4x4(np.matmul(u, s[..., :, None] * v))
                 ca[: rows * 4, : cols * 4] = new.transpose(0, 2, 1, 3).reshape(rows * 4, cols * 4)
-                self.debug = dict(s0=s0, s0_new=s[..., 0].copy(), gap=(s[..., 1] / np.maximum(s0, 1e-30)))
+                self.debug_ch[channel] = dict(s0=s0, s0_new=s[..., 0].copy(), gap=(s[..., 1] / np.maximum(s0, 1e-30)))
+                self.debug = self.debug_ch[channel] if channel == 1 or 1 not in self.debug_ch else self.debug_ch[1]
             yuv[: row // 4 * 4, : col // 4 * 4, channel] = haar_idwt2((ca, hvd))
         return yuv
 
@@ -709,6 +772,23 @@ class DeShufflerOracle:
 
     def degenerate(self, wm):
         return deshuffle(wm, self.length, self.key)
+
+
+# --------------------------------------------------------------------------------------
+# (f)-4  soft read-out -- BUILD EXTENSION, not reference semantics
+# --------------------------------------------------------------------------------------
+def soft_sums(frame_u8: np.ndarray, length: int, alpha=20) -> np.ndarray:
+    """Independent NumPy statement of the engine's optional soft metric (ofmk_detect_soft_rgb8): instead of the hard
+    parity of round(C21/step) (dct_decoder.py:24), every block contributes round(-cos(pi * C21/step) * 2^14) --
+    -2^14 at even multiples (bit 0), +2^14 at odd ones (bit 1), 0 half-way -- to position (block index mod length).
+    Masks, C21 and step are the reference's (DctDecoderOracle); only the last line is the extension."""
+    dec = DctDecoderOracle(alpha=alpha)
+    dec.decode(bgr2yuv_f32(frame_u8.astype(F32)))
+    r = dec.debug["c21"].astype(F64) / (alpha * dec.debug["mask"])
+    sv = np.rint(-np.cos(np.pi * r) * 16384.0).astype(np.int64).reshape(-1)
+    out = np.zeros(length, np.int64)
+    np.add.at(out, np.arange(sv.size) % length, sv)
+    return out
 
 
 # --------------------------------------------------------------------------------------

@@ -41,13 +41,18 @@ def budget(n, frac, floor=1):
     return max(floor, int(np.floor(n * frac)))
 
 
-def determined_pixels(frame, wm, scale=15):
-    enc = orc.DwtDctSvdEncoderOracle()
+def determined_pixels(frame, wm, scales=(0, 15, 0)):
+    """Blocks whose marking is defined to float32 accuracy in EVERY marked channel (see the module text)."""
+    enc = orc.DwtDctSvdEncoderOracle(scales=scales)
     enc.read_wm(wm)
     enc.encode(orc.bgr2yuv_f32(frame.astype(np.float32)))
-    s0, gap = enc.debug["s0"].astype(np.float64), enc.debug["gap"]
-    frac = np.mod(s0, scale)
-    ok = (np.minimum(frac, scale - frac) > 1e-3 * np.maximum(1.0, s0 / 100)) & (gap < 1 - 1e-3)
+    ok = None
+    for ch, dbg in enc.debug_ch.items():
+        scale = float(scales[ch])
+        s0, gap = dbg["s0"].astype(np.float64), dbg["gap"]
+        frac = np.mod(s0, scale)
+        this = (np.minimum(frac, scale - frac) > 1e-3 * np.maximum(1.0, s0 / 100)) & (gap < 1 - 1e-3)
+        ok = this if ok is None else ok & this
     H, W, _ = frame.shape
     m = np.ones((H, W), bool)
     m[: ok.shape[0] * 8, : ok.shape[1] * 8] = np.kron(ok, np.ones((8, 8), bool))
@@ -68,21 +73,27 @@ def test_svd_golden_embed_and_detect(eng, case):
     frame = g["frame"]
     H, W, _ = frame.shape
     N, nblk = H * W // 64, (H // 8) * (W // 8)
-    marked = eng.svd_embed(cuda(frame[None]), g["wm"])[0].cpu().numpy()
-    mask, ok = determined_pixels(frame, g["wm"])
-    assert ok.mean() > 0.9
+    scales = tuple(float(x) for x in g["scales"]) if "scales" in g.files else (0.0, 15.0, 0.0)      # round 2: per-channel scales
+    marked = eng.svd_embed(cuda(frame[None]), g["wm"], scales=scales)[0].cpu().numpy()
+    mask, ok = determined_pixels(frame, g["wm"], scales)
+    assert ok.mean() > (0.9 if sum(x > 0 for x in scales) == 1 else 0.8)
     assert_pixels_close(marked, g["marked"], mask)
     assert np.array_equal(marked[(H // 8) * 8:], frame[(H // 8) * 8:]) and np.array_equal(marked[:, (W // 8) * 8:], frame[:, (W // 8) * 8:])
-    counts, bits = eng.svd_detect(cuda(g["marked"][None]), 8, want_bits=True)
+    if not (scales[0] > 0 or scales[2] > 0):
+        assert np.array_equal(marked[..., 2], frame[..., 2])          # channel 2 untouched when only U is marked
+    counts, bits = eng.svd_detect(cuda(g["marked"][None]), 8, want_bits=True, scales=scales)
     bits = bits[0].cpu().numpy()
     assert bits.shape == (N,) and not bits[nblk:].any()
     assert (bits != g["raw_bits"].reshape(-1)).sum() <= budget(nblk, 1e-4)
     assert np.array_equal(counts[0].cpu().numpy(), np.array([bits[i::8].sum() for i in range(8)]))
-    out = DeShuffler(key=int(g["key"])).set_shape((8,)).degenerate_counts(counts[0].cpu().numpy(), N)
-    assert np.array_equal(out, g["degenerated"])
+    if scales[1] > 0:
+        out = DeShuffler(key=int(g["key"])).set_shape((8,)).degenerate_counts(counts[0].cpu().numpy(), N)
+        assert np.array_equal(out, g["degenerated"])
+    else:                                            # the reference reads channel 1 only (decoder.py:24): zeros
+        assert not bits.any() and not g["raw_bits"].any()
     # fused embed+verify == embed followed by detect
-    o2, c2, b2 = eng.svd_embed_detect(cuda(frame[None]), g["wm"], 8, want_bits=True)
-    c3, b3 = eng.svd_detect(o2, 8, want_bits=True)
+    o2, c2, b2 = eng.svd_embed_detect(cuda(frame[None]), g["wm"], 8, want_bits=True, scales=scales)
+    c3, b3 = eng.svd_detect(o2, 8, want_bits=True, scales=scales)
     import torch
     assert torch.equal(c2, c3) and torch.equal(b2, b3) and np.array_equal(o2[0].cpu().numpy(), marked)
 
@@ -147,7 +158,52 @@ def test_mark_py_and_detect_py_logic_literally(eng):
     ref_bits = orc.DwtDctSvdDecoderOracle().decode(ref)
     assert bits.dtype == np.float64 and bits.shape == ref_bits.shape and (bits != ref_bits).sum() <= 6
     with pytest.raises(NotImplementedError):
-        DwtDctSvdEncoder(scales=[15, 15, 0])
+        DwtDctSvdEncoder(blk=8)
+    with pytest.raises(ValueError):
+        DwtDctSvdEncoder(scales=[0, 0, 0])
+    # per-channel scales at the plugin boundary (dwt_dct_svd_encoder.py:19-26): every marked channel changes
+    sc = [10, 15, 20]
+    enc3 = DwtDctSvdEncoder(scales=sc)
+    enc3.read_wm(wm)
+    ref3 = orc.DwtDctSvdEncoderOracle(scales=sc)
+    ref3.read_wm(wm)
+    want = ref3.encode(yuv.copy())
+    got3 = enc3.encode(yuv.copy())
+    _, ok3 = determined_pixels(frames[0], wm, sc)
+    blk3 = np.kron(ok3, np.ones((8, 8), bool))
+    for ch in range(3):
+        assert np.abs(got3[:, :, ch] - want[:, :, ch])[blk3].max() <= 3e-3, ch
+        assert not np.array_equal(got3[:, :, ch], yuv[:, :, ch])
+    bits3 = DwtDctSvdDecoder(scales=sc).decode(want)
+    assert (bits3 != orc.DwtDctSvdDecoderOracle(scales=sc).decode(want)).sum() <= 6
+    assert not DwtDctSvdDecoder(scales=[12, 0, 0]).decode(want).any()
+
+
+@pytest.mark.parametrize("scales", [(10.0, 15.0, 20.0), (12.0, 0.0, 0.0), (0.0, 0.0, 30.0), (7.5, 22.0, 0.0)])
+def test_svd_per_channel_scales_against_oracle(eng, scales):
+    """DwtDctSvdEncoder(scales=[a, b, c]) (dwt_dct_svd_encoder.py:6,19-26): any subset of the YUV channels marked,
+    each with its own step; the read-out stays channel 1's (dwt_dct_svd_decoder.py:24)."""
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    for (H, W, seed) in [(240, 320, 1001), (1080, 1920, 2000), (36, 52, 6)]:
+        N, nblk = H * W // 64, (H // 8) * (W // 8)
+        frame = orc.synthetic_frame(H, W, seed)
+        wm = orc.shuffle_generate(P8, (1, N), 0)
+        enc = orc.DwtDctSvdEncoderOracle(scales=scales)
+        enc.read_wm(wm)
+        ref = orc.mark_frame(frame, enc)
+        marked, counts, bits = eng.svd_embed_detect(cuda(frame[None]), wm, 8, want_bits=True, scales=scales)
+        mask, ok = determined_pixels(frame, wm, scales)
+        assert_pixels_close(marked[0].cpu().numpy(), ref, mask)
+        ref_bits = orc.check_frame(ref, orc.DwtDctSvdDecoderOracle(scales=scales)).reshape(-1)
+        c2, b2 = eng.svd_detect(cuda(ref[None]), 8, want_bits=True, scales=scales)
+        assert (b2[0].cpu().numpy()[:ref_bits.size] != ref_bits).sum() <= budget(nblk, 1e-4)
+        c3, b3 = eng.svd_detect(marked, 8, want_bits=True, scales=scales)
+        assert torch.equal(c3, counts) and torch.equal(b3, bits)
+        if scales[1] > 0 and nblk >= 32:
+            assert np.array_equal(DeShuffler(key=0).set_shape((8,)).degenerate_counts(counts[0].cpu().numpy(), N), P8)
+        if not scales[1] > 0:
+            assert not bits.any() and not ref_bits.any()
 
 
 def test_svd_random_shapes_and_contents(eng):

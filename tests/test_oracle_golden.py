@@ -150,14 +150,15 @@ def test_svd_codec_bit_exact_against_reference(case, form):
     g = load(case)
     if form == "loop" and g["frame"].shape[0] > 128:
         pytest.skip("loop form only on small frames")
-    enc = orc.DwtDctSvdEncoderOracle(form=form)
+    scales = tuple(g["scales"]) if "scales" in g.files else (0, 15, 0)      # round 2: per-channel scales
+    enc = orc.DwtDctSvdEncoderOracle(form=form, scales=scales)
     wm = orc.shuffle_generate(g["payload"], (1, g["frame"].shape[0] * g["frame"].shape[1] // 64), int(g["key"]))
     assert np.array_equal(wm, g["wm"])
     enc.read_wm(wm)
     if "yuv_in" in g.files:
         assert np.array_equal(enc.encode(g["yuv_in"].copy()), g["yuv_out"])
     assert np.array_equal(orc.mark_frame(g["frame"], enc), g["marked"])
-    dec = orc.DwtDctSvdDecoderOracle(form=form)
+    dec = orc.DwtDctSvdDecoderOracle(form=form, scales=scales)
     raw = orc.check_frame(g["marked"], dec)
     assert raw.shape == g["raw_bits"].shape and np.array_equal(raw, g["raw_bits"])
     assert np.array_equal(orc.deshuffle(raw, g["payload"].size, int(g["key"])), g["degenerated"])
@@ -173,3 +174,55 @@ def test_haar_and_dct4_primitives():
     c = orc.dct4x4(b)
     assert np.allclose(orc.idct4x4(c), b, atol=1e-4)
     assert np.allclose(np.linalg.svd(c, compute_uv=False), np.linalg.svd(b, compute_uv=False), rtol=1e-5)   # DCT is orthonormal
+
+
+# ---- GrayScale / DeGrayScale at scale: the reference's own 480x270 payload image on full frames --------
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+@pytest.mark.parametrize("tag,h,w", [("1080p", 1080, 1920), ("4k", 2160, 3840)])
+def test_grayscale_numbers_payload_at_scale(tag, h, w):
+    """tests/golden/grayscale_numbers_digest.npz holds SHA-256 digests of every stage of the reference's modules
+    (GrayScale / DeGrayScale unmodified; DctEncoder / DctDecoder / Embedder with the restated cv2 primitives: OpenCV's
+    own rounding is parity-unpinned) for tests/media/wms/numbers.jpeg (L = 129 600) on a synthetic frame.  1080p: the
+    image exceeds the capacity (warning, truncation, nan means -> all-zero image); 4K: exactly one block per bit."""
+    import warnings
+    from PIL import Image
+    from conftest import GOLDEN
+    from offmark.degenerator.de_grayscale import DeGrayScale
+    from offmark.generator.grayscale import GrayScale
+    g = load("grayscale_numbers_digest")
+    img = np.asarray(Image.open(os.path.join(GOLDEN, "numbers.jpeg")).convert("L"))
+    assert tuple(g["payload_shape"]) == img.shape == (270, 480)
+    key, alpha = int(g["key"]), float(g["alpha"])
+    frame = orc.synthetic_frame(h, w, int(g[tag + "_seed"]))
+    cap = (1, h * w // 64)
+    wm = orc.grayscale_generate(img, cap, key)
+    assert np.array_equal(_sha(wm.astype(np.uint8)), g[tag + "_wm_sha256"])
+    with warnings.catch_warnings(record=True) as caught:                 # the product's host-side generator, same bits
+        warnings.simplefilter("always")
+        assert np.array_equal(GrayScale(key=key).generate_wm(img, cap), wm)
+    assert bool(caught) == bool(g[tag + "_warned"]) == (img.size > cap[1])
+    # the digests were captured under this container's numpy 2 (NEP 50 promotion inside texture_mask), like every
+    # other reference-run vector: the oracle reproduces them with promotion="nep50" (DESIGN.md 2)
+    enc = orc.DctEncoderOracle(alpha=alpha, promotion="nep50")
+    enc.read_wm(wm)
+    marked = orc.mark_frame(frame, enc)
+    assert np.array_equal(_sha(marked), g[tag + "_marked_sha256"])
+    raw = orc.check_frame(marked, orc.DctDecoderOracle(alpha=alpha, promotion="nep50"))
+    assert np.array_equal(_sha(raw.astype(np.uint8)), g[tag + "_raw_bits_sha256"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        deg = orc.degrayscale(raw, img.shape, key)
+        mine = DeGrayScale(key=key).set_shape(img.shape).degenerate(raw)
+    want = np.unpackbits(g[tag + "_degenerated_packed"])[: img.size].reshape(img.shape) * 255
+    assert np.array_equal(deg, want) and np.array_equal(mine, want)
+    counts = np.array([raw.reshape(-1)[i::img.size].sum() for i in range(min(img.size, raw.size))] + [0] * max(0, img.size - raw.size))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(DeGrayScale(key=key).set_shape(img.shape).degenerate_counts(counts, raw.size), want)
+    if tag == "1080p":
+        assert not want.any()                          # nan threshold: nothing compares greater (de_grayscale.py:20-21)
+    else:
+        assert np.mean((want > 0) == (img > 127)) > 0.999

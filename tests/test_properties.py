@@ -89,3 +89,32 @@ def test_c_oracle_matches_numpy_oracle_on_random_frames(h, w, seed, alpha, legac
     bits_ref = orc.check_frame(ref, orc.DctDecoderOracle(alpha=alpha, promotion=promo)).reshape(-1)
     bits, _ = c_oracle.check_frames(ref[None], alpha=alpha, legacy=legacy)
     assert np.array_equal(bits[0], bits_ref)
+
+
+def test_build_defined_yuv420_conversion_properties():
+    """oracle.yuv420_to_rgb / rgb_to_yuv420 (the conversion is the build's own, not swscale's):
+    studio-swing fixed points, layouts, and stability of the 4:2:0 round trip."""
+    rng = np.random.default_rng(0)
+    for g, y in ((0, 16), (255, 235), (128, 126)):                       # black, white, mid grey
+        yy, u, v = orc.rgb_to_yuv420(np.full((8, 8, 3), g, np.uint8))
+        assert (yy == y).all() and (u == 128).all() and (v == 128).all()
+        assert (np.abs(orc.yuv420_to_rgb(yy, u, v).astype(int) - g) <= 1).all()
+    red = np.zeros((8, 8, 3), np.uint8)
+    red[..., 0] = 255
+    yy, u, v = orc.rgb_to_yuv420(red)
+    assert yy[0, 0] == 81 and u[0, 0] == 90 and v[0, 0] == 240          # BT.601 studio-swing red
+    rgb = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    planes = orc.rgb_to_yuv420(rgb)
+    for layout in ("i420", "nv12"):
+        buf = orc.pack_yuv420(*planes, layout)
+        assert buf.size == 32 * 48 * 3 // 2
+        assert all(np.array_equal(a, b) for a, b in zip(orc.unpack_yuv420(buf, 32, 48, layout), planes))
+    # chroma-flat content survives the round trip to within the two roundings; a second round trip changes little
+    flat = np.broadcast_to(rng.integers(30, 220, 3, dtype=np.uint8), (16, 16, 3)).copy()
+    once = orc.yuv420_to_rgb(*orc.rgb_to_yuv420(flat))
+    twice = orc.yuv420_to_rgb(*orc.rgb_to_yuv420(once))
+    assert np.abs(once.astype(int) - flat).max() <= 2 and np.abs(twice.astype(int) - once).max() <= 1
+    # every input byte combination stays in range (clip) -- including illegal studio-swing values
+    y, u, v = (rng.integers(0, 256, s, dtype=np.uint8) for s in ((16, 16), (8, 8), (8, 8)))
+    out = orc.yuv420_to_rgb(y, u, v)
+    assert out.dtype == np.uint8 and out.shape == (16, 16, 3)

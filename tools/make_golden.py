@@ -77,10 +77,12 @@ def run_case(name, frame, payload, key, alpha, image_payload=False, store_yuv=Fa
           f"raw_ber={np.mean(raw_bits.reshape(-1)[:wm.size] != wm.reshape(-1)):.4f} payload_ok={ok}")
 
 
-def run_svd_case(name, frame, payload, key, store_yuv=False):
-    """mark.py / detect.py's codec pair (DwtDctSvdEncoder / DwtDctSvdDecoder) on one frame."""
+def run_svd_case(name, frame, payload, key, store_yuv=False, scales=None):
+    """mark.py / detect.py's codec pair (DwtDctSvdEncoder / DwtDctSvdDecoder) on one frame.
+    scales: per-channel quantisation steps (dwt_dct_svd_encoder.py:6,19-26); None = the reference's default [0,15,0]."""
     h, w, _ = frame.shape
-    enc, dec = DwtDctSvdEncoder(), DwtDctSvdDecoder()
+    enc, dec = (DwtDctSvdEncoder(), DwtDctSvdDecoder()) if scales is None else \
+        (DwtDctSvdEncoder(scales=list(scales)), DwtDctSvdDecoder(scales=list(scales)))
     wm = Shuffler(key=key).generate_wm(payload, enc.wm_capacity((h, w, 3)))
     enc.read_wm(wm)
     deg = DeShuffler(key=key).set_shape(payload.shape)
@@ -90,6 +92,8 @@ def run_svd_case(name, frame, payload, key, store_yuv=False):
     raw_bits = dec.decode(cv2.cvtColor(marked.astype(np.float32), cv2.COLOR_BGR2YUV))
     d = dict(frame=frame, payload=np.asarray(payload), key=np.int64(key), wm=wm, marked=marked, raw_bits=raw_bits,
              raw_bits_clean=dec.decode(yuv_out.copy()), degenerated=deg.degenerate(raw_bits))
+    if scales is not None:
+        d["scales"] = np.asarray(scales, dtype=np.float64)
     if store_yuv:
         d.update(yuv_in=yuv_in, yuv_out=yuv_out)
     np.savez_compressed(os.path.join(OUT, "svd_" + name + ".npz"), **d)
@@ -97,7 +101,56 @@ def run_svd_case(name, frame, payload, key, store_yuv=False):
           f"payload_ok={np.array_equal(d['degenerated'], payload)}")
 
 
+def svd_scale_cases():
+    """Round 2: per-channel scales of the DwtDctSvd codec (any subset of the three channels marked)."""
+    from PIL import Image
+    P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    nat = np.asarray(Image.open("/root/reference/tests/media/imgs/frame63.jpeg").convert("RGB"))
+    run_svd_case("scales_10_15_20_syn_64x96", orc.synthetic_frame(64, 96, 2), P8, 0, store_yuv=True, scales=(10, 15, 20))
+    run_svd_case("scales_12_0_0_syn_64x96", orc.synthetic_frame(64, 96, 3), P8, 0, store_yuv=True, scales=(12, 0, 0))
+    run_svd_case("scales_0_9_25_syn_36x52", orc.synthetic_frame(36, 52, 6), P8, 7, store_yuv=True, scales=(0, 9, 25))
+    run_svd_case("scales_0_0_30_syn_240x320", orc.synthetic_frame(240, 320, 1001), P8, 0, scales=(0, 0, 30))
+    run_svd_case("scales_8_22_8_frame63_crop0", np.ascontiguousarray(nat[300:428, 600:728]), P8, 0, scales=(8, 22, 8))
+
+
+def grayscale_at_scale_digests():
+    """Round 2: GrayScale / DeGrayScale with the reference's own 480x270 payload image
+    (tests/media/wms/numbers.jpeg, L = 129 600 bits) on full frames.  The frames are synthetic and regenerable, the
+    outputs are too large to store: SHA-256 digests of every stage plus the small decoded image.
+    1080p: capacity 32 400 < L, so GrayScale warns and truncates and DeGrayScale's means of empty slices are nan
+    (de_grayscale.py:17-21): the reference decodes an all-zero image.  4K: capacity == L, one block per payload bit."""
+    import hashlib
+    import warnings
+    from PIL import Image
+    img = np.asarray(Image.open("/root/reference/tests/media/wms/numbers.jpeg").convert("L"))
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)      # noqa: E731
+    out = dict(payload_shape=np.asarray(img.shape), key=np.int64(3), alpha=np.float64(20))
+    for tag, (h, w, seed) in (("1080p", (1080, 1920, 2000)), ("4k", (2160, 3840, 3001))):
+        frame = orc.synthetic_frame(h, w, seed)
+        enc, dec = DctEncoder(alpha=20), DctDecoder(alpha=20)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            wm = GrayScale(key=3).generate_wm(img, enc.wm_capacity(frame.shape))
+        enc.read_wm(wm)
+        marked = Embedder(None, enc, None)._Embedder__mark_frame(frame)
+        raw = dec.decode(cv2.cvtColor(marked.astype(np.float32), cv2.COLOR_BGR2YUV))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            deg = DeGrayScale(key=3).set_shape(img.shape).degenerate(raw)
+        out.update({f"{tag}_seed": np.int64(seed), f"{tag}_warned": np.bool_(len(caught) > 0), f"{tag}_wm_sha256": sha(wm.astype(np.uint8)),
+                    f"{tag}_marked_sha256": sha(marked), f"{tag}_raw_bits_sha256": sha(raw.astype(np.uint8)),
+                    f"{tag}_degenerated_packed": np.packbits(deg.reshape(-1) > 0), f"{tag}_raw_ber": np.float64(np.mean(raw.reshape(-1) != wm.reshape(-1))),
+                    f"{tag}_image_agreement": np.float64(np.mean((deg > 0) == (img > 127)))})
+        print(f"grayscale_numbers {tag}: warned={len(caught) > 0} raw_ber={out[f'{tag}_raw_ber']:.4f} "
+              f"decoded image agrees with the payload on {out[f'{tag}_image_agreement']:.4f} of its pixels")
+    np.savez_compressed(os.path.join(OUT, "grayscale_numbers_digest.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--round2":       # add the round-2 fixtures without touching round 1's
+        svd_scale_cases()
+        grayscale_at_scale_digests()
+        return
     P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
     run_svd_case("syn_64x96", orc.synthetic_frame(64, 96, 2), P8, 0, store_yuv=True)
     run_svd_case("syn_240x320", orc.synthetic_frame(240, 320, 1001), P8, 0)
@@ -163,6 +216,10 @@ def main():
                 rows[tag + "_back"] = back
     np.savez_compressed(os.path.join(OUT, "payload_codecs.npz"), **rows)
     print("payload_codecs", len(rows) // 4, "cases")
+
+
+    svd_scale_cases()
+    grayscale_at_scale_digests()
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@
 #include "dct_kernels.hiph"
 #include "svd_kernels.hiph"
 #include "misc_kernels.hiph"
+#include "planar_kernels.hiph"
 
 namespace {
 
@@ -322,10 +323,13 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
         if (b.bits) b.bits += (size_t)f0 * a.N;
         const dim3 grid = block_grid(g, cf);
         ScopedTiming timing(KIND_SVD, cx);
-#define OFMK_SVD_LAUNCH(AL, MD) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
-        if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT); else OFMK_SVD_LAUNCH(false, SVD_DETECT); }
-        else if (mode == SVD_EMBED) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED); else OFMK_SVD_LAUNCH(false, SVD_EMBED); }
-        else { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED_VERIFY); else OFMK_SVD_LAUNCH(false, SVD_EMBED_VERIFY); }
+#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
+        const bool multi = a.scales[0] > 0.f || a.scales[2] > 0.f || !(a.scales[1] > 0.f);      // anything but the default [0, s, 0]
+        if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT, false); else OFMK_SVD_LAUNCH(false, SVD_DETECT, false); }
+        else if (mode == SVD_EMBED && !multi) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED, false); else OFMK_SVD_LAUNCH(false, SVD_EMBED, false); }
+        else if (mode == SVD_EMBED) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED, true); else OFMK_SVD_LAUNCH(false, SVD_EMBED, true); }
+        else if (!multi) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED_VERIFY, false); else OFMK_SVD_LAUNCH(false, SVD_EMBED_VERIFY, false); }
+        else { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED_VERIFY, true); else OFMK_SVD_LAUNCH(false, SVD_EMBED_VERIFY, true); }
 #undef OFMK_SVD_LAUNCH
     }
     HIP_TRY(hipGetLastError());
@@ -333,6 +337,76 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
         hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
         HIP_TRY(hipGetLastError());
     }
+    return OFMK_OK;
+}
+
+// ---- planar YUV 4:2:0 (I420 / NV12) -------------------------------------------------------------
+int check_planar(int layout, int H, int W, const void *a, const void *b) {
+    if (layout != OFMK_YUV_I420 && layout != OFMK_YUV_NV12) return fail(OFMK_E_ARG, "layout must be OFMK_YUV_I420 or OFMK_YUV_NV12%s");
+    if (H % 8 || W % 8) return fail(OFMK_E_ARG, "planar 4:2:0 entry points need H and W to be multiples of 8%s");
+    if ((a && (uintptr_t)a % 8) || (b && (uintptr_t)b % 8)) return fail(OFMK_E_ARG, "planar frame buffers must be 8-byte aligned%s");
+    return OFMK_OK;
+}
+
+PGeom make_pgeom(int layout, int H, int W, size_t plane) {
+    PGeom g;
+    g.W = W;
+    g.wb = W / 8;
+    g.inv_wb = 1.0f / (float)g.wb;
+    g.nblk = (H / 8) * (W / 8);
+    g.frame_stride = (size_t)H * W * 3 / 2;
+    g.u_off = (size_t)H * W;
+    g.v_off = layout == OFMK_YUV_I420 ? g.u_off + (size_t)H * W / 4 : g.u_off + 1;
+    g.cpitch = layout == OFMK_YUV_I420 ? W / 2 : W;
+    g.plane = plane;
+    return g;
+}
+
+int launch_analyze_yuv420(const uint8_t *frames, int layout, int n, int H, int W, const Workspace &ws, const Ctx &cx,
+                          int32_t *zero_counts = nullptr, int L = 0) {
+    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, cx.s));
+    const PGeom g = make_pgeom(layout, H, W, ws.plane);
+    const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);
+    ScopedTiming timing(KIND_PLANAR, cx);
+    if (layout == OFMK_YUV_I420) OFMK_TIMED_LAUNCH(timing, analyze_yuv420_kernel<FMT_I420>, grid, dim3(kThreads), 0, cx.s, frames, g, ws.rec, ws.ysum, zero_counts, L);
+    else OFMK_TIMED_LAUNCH(timing, analyze_yuv420_kernel<FMT_NV12>, grid, dim3(kThreads), 0, cx.s, frames, g, ws.rec, ws.ysum, zero_counts, L);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int launch_mark_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
+                       double alpha, const Workspace &ws, bool fused, const Ctx &cx) {
+    const PGeom g = make_pgeom(layout, H, W, ws.plane);
+    const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);
+    MarkArgs m;
+    m.rec = ws.rec;
+    m.ysum = ws.ysum;
+    m.wm = wm;
+    m.wm_row = wm_row;
+    m.N = (int)((long long)H * W / 64);
+    m.alpha = alpha;
+    ScopedTiming timing(KIND_PLANAR, cx);
+    if (layout == OFMK_YUV_I420) {
+        if (fused) OFMK_TIMED_LAUNCH(timing, (mark_yuv420_kernel<FMT_I420, true>), grid, dim3(kThreads), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2);
+        else OFMK_TIMED_LAUNCH(timing, (mark_yuv420_kernel<FMT_I420, false>), grid, dim3(kThreads), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2);
+    } else {
+        if (fused) OFMK_TIMED_LAUNCH(timing, (mark_yuv420_kernel<FMT_NV12, true>), grid, dim3(kThreads), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2);
+        else OFMK_TIMED_LAUNCH(timing, (mark_yuv420_kernel<FMT_NV12, false>), grid, dim3(kThreads), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2);
+    }
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+// scales: host double[3], one per YUV channel (dwt_dct_svd_encoder.py:6: scales=[0,15,0]); <= 0 leaves a channel alone
+int set_scales(SvdArgs &a, const double *scales, bool need_channel1) {
+    if (!scales) return fail(OFMK_E_ARG, "scales is null (host array of 3 doubles)%s");
+    bool any = false;
+    for (int k = 0; k < 3; ++k) {
+        if (!(scales[k] == scales[k]) || scales[k] > 1e30) return fail(OFMK_E_ARG, "scales must be finite%s");
+        a.scales[k] = scales[k] > 0 ? (float)scales[k] : 0.f;
+        any |= scales[k] > 0;
+    }
+    if (!any && !need_channel1) return fail(OFMK_E_ARG, "no channel has a positive scale%s");
     return OFMK_OK;
 }
 
@@ -514,49 +588,57 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, c
 }
 
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
-                        const int32_t *wm_row, double scale, void *stream, const ofmk_opts *opts) {
+                        const int32_t *wm_row, const double *scales, void *stream, const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
-    if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
-    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
+    if ((rc = set_scales(a, scales, false))) return rc;
+    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1;
     return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED, a, make_ctx(stream, opts));
 }
 
-int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double scale, int32_t *counts, uint8_t *bits,
+// scales[1] <= 0: the reference's decoder returns channel 1's (never written) bit array: all zeros
+int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales, int32_t *counts, uint8_t *bits,
                          void *stream, const ofmk_opts *opts) {
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
-    if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
-    a.counts = counts; a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = L; a.scale = (float)scale;
+    if ((rc = set_scales(a, scales, true))) return rc;
+    a.counts = counts; a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = L;
+    if (!(a.scales[1] > 0.f)) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
+        if (bits) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
+        return OFMK_OK;
+    }
     return launch_svd_rgb8(in, nullptr, n, H, W, SVD_DETECT, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
-                               const int32_t *wm_row, double scale, int L, int32_t *counts, uint8_t *bits,
+                               const int32_t *wm_row, const double *scales, int L, int32_t *counts, uint8_t *bits,
                                void *stream, const ofmk_opts *opts) {
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
-    if (!(scale > 0)) return fail(OFMK_E_ARG, "scale must be positive%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
+    if ((rc = set_scales(a, scales, false))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.counts = counts; a.bits = bits;
-    a.N = (int)((long long)H * W / 64); a.L = L; a.scale = (float)scale;
+    a.N = (int)((long long)H * W / 64); a.L = L;
     return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
-                           double scale, void *stream) {
+                           const double *scales, void *stream) {
     int rc = check_embed_args(yuv, yuv, n, H, W, wm, n_wm);
     if (rc) return rc;
-    if (!(scale > 0) || n > kMaxChunk) return fail(OFMK_E_ARG, "bad scale or too many frames%s");
+    if (n > kMaxChunk) return fail(OFMK_E_ARG, "too many frames%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
-    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
+    if ((rc = set_scales(a, scales, false))) return rc;
+    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1;
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
@@ -565,19 +647,21 @@ int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, i
     return OFMK_OK;
 }
 
-int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, double scale, uint8_t *bits, void *stream) {
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream) {
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!yuv || !bits) return fail(OFMK_E_ARG, "null pointer%s");
-    if (!(scale > 0) || n > kMaxChunk) return fail(OFMK_E_ARG, "bad scale or too many frames%s");
+    if (n > kMaxChunk) return fail(OFMK_E_ARG, "too many frames%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
-    a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = 1; a.scale = (float)scale;
+    if ((rc = set_scales(a, scales, true))) return rc;
+    a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = 1;
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.N > g.nblk) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
+    if (a.N > g.nblk || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
+    if (!(a.scales[1] > 0.f)) return OFMK_OK;
     hipLaunchKernelGGL((svd_yuv32f_kernel<SVD_DETECT>), block_grid(g, n), dim3(kThreads), 0, s, const_cast<float *>(yuv), g, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
@@ -589,6 +673,110 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
     if (n < 1 || L < 1 || n_bits < 0) return fail(OFMK_E_ARG, "bad sizes%s");
     hipLaunchKernelGGL(degenerate_kernel, dim3((unsigned)n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), counts,
                        L, n_bits, perm, payload);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+// ---- planar YUV 4:2:0 entry points ------------------------------------------------------
+int ofmk_embed_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, int n_wm,
+                      const int32_t *wm_row, double alpha, int chunk_frames, void *workspace, size_t workspace_bytes,
+                      void *stream, const ofmk_opts *opts) {
+    int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
+    if (rc) return rc;
+    if ((rc = check_planar(layout, H, W, in, out))) return rc;
+    Workspace ws;
+    if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
+    const Ctx cx = make_ctx(stream, opts);
+    const size_t fs = (size_t)H * W * 3 / 2;
+    for (int f0 = 0; f0 < n; f0 += ws.frames) {
+        const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
+        if ((rc = launch_analyze_yuv420(in + (size_t)f0 * fs, layout, cf, H, W, ws, cx))) return rc;
+        if ((rc = launch_mark_yuv420(in + (size_t)f0 * fs, out + (size_t)f0 * fs, layout, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr,
+                                     alpha, ws, false, cx))) return rc;
+    }
+    return OFMK_OK;
+}
+
+int ofmk_detect_yuv420(const uint8_t *in, int layout, int n, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    int rc = check_detect_args(in, n, H, W, L, counts, bits);
+    if (rc) return rc;
+    if ((rc = check_planar(layout, H, W, in, nullptr))) return rc;
+    Workspace ws;
+    if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
+    const Ctx cx = make_ctx(stream, opts);
+    const size_t fs = (size_t)H * W * 3 / 2;
+    for (int f0 = 0; f0 < n; f0 += ws.frames) {
+        const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
+        if ((rc = launch_analyze_yuv420(in + (size_t)f0 * fs, layout, cf, H, W, ws, cx, counts ? counts + (size_t)f0 * L : nullptr, L))) return rc;
+        if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, false, cx))) return rc;
+    }
+    return OFMK_OK;
+}
+
+int ofmk_embed_detect_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, int n_wm,
+                             const int32_t *wm_row, double alpha, int L, int32_t *counts, uint8_t *bits, int chunk_frames,
+                             void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
+    if (rc) return rc;
+    if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
+    if ((rc = check_planar(layout, H, W, in, out))) return rc;
+    Workspace ws;
+    if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
+    const Ctx cx = make_ctx(stream, opts);
+    const size_t fs = (size_t)H * W * 3 / 2;
+    const bool fused = !(cx.flags & OFMK_F_SEPARATE_DETECT);
+    for (int f0 = 0; f0 < n; f0 += ws.frames) {
+        const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
+        const uint8_t *pin = in + (size_t)f0 * fs;
+        uint8_t *pout = out + (size_t)f0 * fs;
+        int32_t *zc = counts ? counts + (size_t)f0 * L : nullptr;
+        if ((rc = launch_analyze_yuv420(pin, layout, cf, H, W, ws, cx, fused ? zc : nullptr, L))) return rc;
+        if ((rc = launch_mark_yuv420(pin, pout, layout, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, fused, cx))) return rc;
+        if (fused) {
+            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, cx))) return rc;
+        } else {
+            if ((rc = launch_analyze_yuv420(pout, layout, cf, H, W, ws, cx, zc, L))) return rc;
+            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, false, cx))) return rc;
+        }
+    }
+    return OFMK_OK;
+}
+
+int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int H, int W, void *stream) {
+    int rc = check_dims(n, H, W);
+    if (rc) return rc;
+    if (!yuv || !rgb) return fail(OFMK_E_ARG, "null pointer%s");
+    if ((rc = check_planar(layout, H, W, yuv, rgb))) return rc;
+    const PGeom g = make_pgeom(layout, H, W, 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
+        const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
+        const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)cf);
+        const uint8_t *pi = yuv + (size_t)f0 * g.frame_stride;
+        uint8_t *po = rgb + (size_t)f0 * H * W * 3;
+        if (layout == OFMK_YUV_I420) hipLaunchKernelGGL(yuv420_to_rgb8_kernel<FMT_I420>, grid, dim3(kThreads), 0, s, pi, po, g);
+        else hipLaunchKernelGGL(yuv420_to_rgb8_kernel<FMT_NV12>, grid, dim3(kThreads), 0, s, pi, po, g);
+    }
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int H, int W, void *stream) {
+    int rc = check_dims(n, H, W);
+    if (rc) return rc;
+    if (!yuv || !rgb) return fail(OFMK_E_ARG, "null pointer%s");
+    if ((rc = check_planar(layout, H, W, yuv, rgb))) return rc;
+    const PGeom g = make_pgeom(layout, H, W, 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
+        const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
+        const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)cf);
+        const uint8_t *pi = rgb + (size_t)f0 * H * W * 3;
+        uint8_t *po = yuv + (size_t)f0 * g.frame_stride;
+        if (layout == OFMK_YUV_I420) hipLaunchKernelGGL(rgb8_to_yuv420_kernel<FMT_I420>, grid, dim3(kThreads), 0, s, pi, po, g);
+        else hipLaunchKernelGGL(rgb8_to_yuv420_kernel<FMT_NV12>, grid, dim3(kThreads), 0, s, pi, po, g);
+    }
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }

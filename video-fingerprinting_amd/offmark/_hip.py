@@ -21,10 +21,12 @@ class Opts(C.Structure):
 
 
 F_SEPARATE_DETECT = 1
+YUV_I420, YUV_NV12 = 0, 1
 TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar")
 
 _vp, _i32, _f64, _sz, _u32 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint
 _op = C.POINTER(Opts)
+_dp = C.POINTER(C.c_double)
 
 #: every symbol include/offmark_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -41,12 +43,18 @@ SIGNATURES = {
     "ofmk_debug_planes": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ofmk_stage_analyze_rgb8": (_i32, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _op]),
     "ofmk_stage_mark_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
-    "ofmk_svd_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _vp, _op]),
-    "ofmk_svd_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _op]),
-    "ofmk_svd_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _vp, _op]),
-    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _vp]),
-    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp]),
+    "ofmk_svd_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp, _op]),
+    "ofmk_svd_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _dp, _vp, _vp, _vp, _op]),
+    "ofmk_svd_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _vp, _vp, _vp, _op]),
+    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp]),
+    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _dp, _vp, _vp]),
     "ofmk_payloads_from_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ofmk_embed_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_detect_yuv420": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_embed_detect_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _i32, _vp,
+                                        _sz, _vp, _op]),
+    "ofmk_yuv420_to_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ofmk_rgb8_to_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ofmk_hbm_copy": (_i32, [_vp, _vp, _sz, _vp]),
     "ofmk_hbm_read": (_i32, [_vp, _sz, _vp, _vp]),
     "ofmk_timing_create": (_i32, [_i32, _u32, C.POINTER(_vp)]),
@@ -117,6 +125,15 @@ class Timing:
             self.close()
         except Exception:
             pass
+
+
+def scales3(scale=15, scales=None):
+    """ctypes double[3] for the DwtDctSvd entry points: `scales` = per-channel list as in
+    DwtDctSvdEncoder(scales=[0,15,0]), or the single channel-1 `scale`."""
+    v = [0.0, float(scale), 0.0] if scales is None else [float(x) for x in scales]
+    if len(v) != 3:
+        raise ValueError("scales needs three entries (one per YUV channel)")
+    return (C.c_double * 3)(*v)
 
 
 def opts_ref(o):

@@ -1,19 +1,26 @@
 """DwtDctSvdEncoder on the MI355X.  Mirrors offmark.embed.dwt_dct_svd_encoder.DwtDctSvdEncoder
 (reference src/offmark/embed/dwt_dct_svd_encoder.py:5-45): DwtDctSvdEncoder(key=None,
 scales=[0,15,0], blk=4), read_wm(wm), wm_capacity(frame_shape), encode(yuv) (mutates and returns).
-This is the codec tests/mark.py constructs.  Supported configuration: the reference's default shape,
-i.e. only channel 1 carries a mark (scales = [0, s, 0]) and blk = 4.  No CPU fallback."""
+This is the codec tests/mark.py constructs.  Any per-channel ``scales`` are supported (every channel with a
+positive scale is marked with the same watermark, dwt_dct_svd_encoder.py:19-26); ``blk`` must be 4: with
+another block size the reference's loop count (row*col/4/blk^2) no longer matches its own capacity
+(row*col//64, dwt_dct_svd_encoder.py:14-17) and it either leaves watermark bits unused or indexes past them.
+No CPU fallback."""
 import numpy as np
 
 from ..engine import DctEngine
 
 
-def _single_scale(scales, blk):
-    scales = list(scales)
-    if blk != 4 or len(scales) != 3 or scales[0] > 0 or scales[2] > 0 or not scales[1] > 0:
-        raise NotImplementedError("the HIP DwtDctSvd codec supports scales=[0, s, 0] with s > 0 and blk=4 "
-                                  "(the reference's defaults); got scales=%r blk=%r" % (scales, blk))
-    return scales[1]
+def _check_scales(scales, blk, need_a_mark=True):
+    scales = [float(x) for x in scales]
+    if len(scales) != 3:
+        raise ValueError("scales needs three entries (one per YUV channel); got %r" % (scales,))
+    if blk != 4:
+        raise NotImplementedError("the HIP DwtDctSvd codec implements blk=4 (the reference's default, the only value "
+                                  "for which its capacity and its block loop agree); got blk=%r" % (blk,))
+    if need_a_mark and not any(x > 0 for x in scales):
+        raise ValueError("no channel has a positive scale: nothing would be marked")
+    return scales
 
 
 class DwtDctSvdEncoder:
@@ -21,7 +28,7 @@ class DwtDctSvdEncoder:
         self.key = key
         self.scales = scales
         self.blk = blk
-        self._scale = _single_scale(scales, blk)
+        self._scales = _check_scales(scales, blk)
         self.wm = None
         self._engine = None
         self._wm_dev = None
@@ -56,12 +63,15 @@ class DwtDctSvdEncoder:
         t = self.engine.torch
         h, w, _ = yuv.shape
         dev = t.from_numpy(np.ascontiguousarray(yuv)).to(self.engine.device).unsqueeze(0)
-        self.engine.svd_encode_yuv(dev, self._device_wm(h * w // 64), scale=self._scale)
-        yuv[:, :, 1] = dev[0, :, :, 1].cpu().numpy()
+        self.engine.svd_encode_yuv(dev, self._device_wm(h * w // 64), scales=self._scales)
+        back = dev[0].cpu().numpy()
+        for ch in range(3):
+            if self._scales[ch] > 0:
+                yuv[:, :, ch] = back[:, :, ch]
         return yuv
 
     def encode_frames_u8(self, frames, out=None, wm_rows=None, wm_table=None):
         """frames: CUDA uint8 [n, H, W, 3]: the whole reference frame step (embedder.py:33-39) on device."""
         n, h, w, _ = frames.shape
         wm = wm_table if wm_table is not None else self._device_wm(h * w // 64)
-        return self.engine.svd_embed(frames, wm, scale=self._scale, wm_row=wm_rows, out=out)
+        return self.engine.svd_embed(frames, wm, scales=self._scales, wm_row=wm_rows, out=out)

@@ -163,6 +163,82 @@ class DctEngine:
                                                       out.data_ptr(), _hip.current_stream()))
         return out
 
+    # -- planar 8-bit YUV 4:2:0 in and out (what a decoder hands over / an encoder takes) -----------
+    _LAYOUT = {"i420": _hip.YUV_I420, "nv12": _hip.YUV_NV12}
+
+    def _check_planar(self, planes, H, W):
+        t = self.torch
+        if H % 8 or W % 8:
+            raise ValueError("planar 4:2:0 frames need H and W to be multiples of 8")
+        if not (isinstance(planes, t.Tensor) and planes.is_cuda and planes.dtype == t.uint8 and planes.dim() == 2
+                and planes.shape[1] == H * W * 3 // 2 and planes.is_contiguous()):
+            raise ValueError("planes must be a contiguous CUDA uint8 tensor [n, H*W*3/2] (I420: Y|U|V, NV12: Y|UV per frame)")
+        return planes.shape[0]
+
+    def embed_yuv420(self, planes, H, W, wm, alpha=20, wm_row=None, out=None, layout="i420"):
+        """Mark frames given as 4:2:0 planes [n, 1.5*H*W]; returns marked planes of the same layout.  Equal, bit for
+        bit, to yuv420_to_rgb -> embed -> rgb_to_yuv420 with the build-defined conversion."""
+        t = self.torch
+        n = self._check_planar(planes, H, W)
+        wm = self._wm(wm, H * W // 64)
+        rows = self._rows(wm_row, n, wm.shape[0])
+        if out is None:
+            out = t.empty_like(planes)
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_embed_yuv420(planes.data_ptr(), out.data_ptr(), self._LAYOUT[layout], n, H, W, wm.data_ptr(),
+                                              wm.shape[0], _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
+                                              _hip.current_stream(), _hip.opts_ref(self.opts)))
+        return out
+
+    def detect_yuv420(self, planes, H, W, L, alpha=20, want_bits=False, layout="i420"):
+        t = self.torch
+        n = self._check_planar(planes, H, W)
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_detect_yuv420(planes.data_ptr(), self._LAYOUT[layout], n, H, W, int(L), float(alpha),
+                                               counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
+                                               _hip.current_stream(), _hip.opts_ref(self.opts)))
+        return counts, bits
+
+    def embed_detect_yuv420(self, planes, H, W, wm, L, alpha=20, wm_row=None, out=None, want_bits=False, layout="i420"):
+        """Mark and verify on planes; counts/bits are what a reader of the WRITTEN planes gets."""
+        t = self.torch
+        n = self._check_planar(planes, H, W)
+        wm = self._wm(wm, H * W // 64)
+        rows = self._rows(wm_row, n, wm.shape[0])
+        if out is None:
+            out = t.empty_like(planes)
+        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
+        cf = self._chunk(n, H, W)
+        ws = self.workspace(H, W, cf)
+        _hip.check(self.lib.ofmk_embed_detect_yuv420(planes.data_ptr(), out.data_ptr(), self._LAYOUT[layout], n, H, W,
+                                                     wm.data_ptr(), wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
+                                                     counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
+                                                     _hip.current_stream(), _hip.opts_ref(self.opts)))
+        return out, counts, bits
+
+    def yuv420_to_rgb(self, planes, H, W, layout="i420"):
+        t = self.torch
+        n = self._check_planar(planes, H, W)
+        rgb = t.empty((n, H, W, 3), dtype=t.uint8, device=self.device)
+        _hip.check(self.lib.ofmk_yuv420_to_rgb8(planes.data_ptr(), rgb.data_ptr(), self._LAYOUT[layout], n, H, W,
+                                                _hip.current_stream()))
+        return rgb
+
+    def rgb_to_yuv420(self, frames, layout="i420"):
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        if H % 8 or W % 8:
+            raise ValueError("planar 4:2:0 frames need H and W to be multiples of 8")
+        planes = t.empty((n, H * W * 3 // 2), dtype=t.uint8, device=self.device)
+        _hip.check(self.lib.ofmk_rgb8_to_yuv420(frames.data_ptr(), planes.data_ptr(), self._LAYOUT[layout], n, H, W,
+                                                _hip.current_stream()))
+        return planes
+
     # -- float32 YUV path (the literal encode(yuv)/decode(yuv) plugin boundary) ------------------
     def encode_yuv(self, yuv, wm, alpha=20, wm_row=None):
         t = self.torch
@@ -188,7 +264,7 @@ class DctEngine:
         return counts, bits
 
     # -- DwtDctSvd codec (one pass, no workspace) ---------------------------------------------------
-    def svd_embed(self, frames, wm, scale=15, wm_row=None, out=None):
+    def svd_embed(self, frames, wm, scale=15, wm_row=None, out=None, scales=None):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
@@ -196,20 +272,20 @@ class DctEngine:
         if out is None:
             out = t.empty_like(frames)
         _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
-                                                _hip.ptr(rows), float(scale), _hip.current_stream(),
+                                                _hip.ptr(rows), _hip.scales3(scale, scales), _hip.current_stream(),
                                                 _hip.opts_ref(self.opts)))
         return out
 
-    def svd_detect(self, frames, L, scale=15, want_bits=False):
+    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
-        _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), float(scale), counts.data_ptr(),
+        _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), _hip.scales3(scale, scales), counts.data_ptr(),
                                                  _hip.ptr(bits), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return counts, bits
 
-    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False):
+    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
@@ -219,24 +295,24 @@ class DctEngine:
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
-                                                       wm.shape[0], _hip.ptr(rows), float(scale), int(L),
+                                                       wm.shape[0], _hip.ptr(rows), _hip.scales3(scale, scales), int(L),
                                                        counts.data_ptr(), _hip.ptr(bits), _hip.current_stream(),
                                                        _hip.opts_ref(self.opts)))
         return out, counts, bits
 
-    def svd_encode_yuv(self, yuv, wm, scale=15):
+    def svd_encode_yuv(self, yuv, wm, scale=15, scales=None):
         t = self.torch
         n, H, W = self._check_frames(yuv, t.float32)
         wm = self._wm(wm, H * W // 64)
         _hip.check(self.lib.ofmk_svd_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], None,
-                                                   float(scale), _hip.current_stream()))
+                                                   _hip.scales3(scale, scales), _hip.current_stream()))
         return yuv
 
-    def svd_decode_yuv(self, yuv, scale=15):
+    def svd_decode_yuv(self, yuv, scale=15, scales=None):
         t = self.torch
         n, H, W = self._check_frames(yuv, t.float32)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device)
-        _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, float(scale), bits.data_ptr(),
+        _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, _hip.scales3(scale, scales), bits.data_ptr(),
                                                    _hip.current_stream()))
         return bits
 
