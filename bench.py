@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--separate-detect", action="store_true",
                     help="embed, then detect the written frames with the stand-alone detect kernels (analyze runs twice, "
                          "12 B/px of traffic) instead of the fused mark+verify kernel; same results bit for bit")
+    ap.add_argument("--onepass", type=int, default=-1, metavar="GRID",
+                    help="DCT codec: one-pass embed+verify (pixels stay in registers across the frame-mean dependency, 6 B/px of "
+                         "traffic); GRID = waves of the persistent kernel, 0 = what the device holds")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
                     help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
@@ -197,7 +200,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _hip.load()
-    flags = _hip.F_SEPARATE_DETECT if a.separate_detect else 0
+    flags = _hip.F_SEPARATE_DETECT if a.separate_detect else (_hip.F_ONEPASS if a.onepass >= 0 else 0)
+    op_grid = max(a.onepass, 0)
 
     # ---- workload ------------------------------------------------------------------------------------
     cfg = a.config
@@ -257,8 +261,8 @@ def main():
     n_chunks = max(1, (n + chunk - 1) // chunk)
     timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
     timing = None if a.no_kernel_events else _hip.Timing(6 * n_chunks * timed_steps + 16)
-    opts_plain = _hip.Opts(flags, 0, None)
-    opts_timed = timing.opts(flags) if timing else opts_plain
+    opts_plain = _hip.Opts(flags, op_grid, None)
+    opts_timed = timing.opts(flags, op_grid) if timing else opts_plain
     lanes = [dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain), out=out, stream=torch.cuda.current_stream())]
     if a.streams == 2:
         lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain),
@@ -402,11 +406,48 @@ def main():
                                              "bit-identical results",
                                         votes_ok=all(np.array_equal(v[0], expected[s]) for s, v in v2.items()))
 
+    # planar 4:2:0 frames through the same step, HBM-resident: what the fused ingest/egress costs or saves
+    if cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras and H % 8 == 0 and W % 8 == 0:
+        e0 = lanes[0]["eng"]
+        planes = e0.rgb_to_yuv420(frames)
+        pout = torch.empty_like(planes)
+
+        def planar_step():
+            _, c, _ = e0.embed_detect_yuv420(planes, H, W, wm_dev, PAYLOAD.size, alpha=a.alpha, out=pout)
+            return e0.payloads(c, N, perm_dev)
+        planar_step()
+        fence()
+        t0 = time.perf_counter()
+        k3 = max(3, min(a.steps, 20))
+        for _ in range(k3):
+            pm = planar_step()
+        fence()
+        el3 = time.perf_counter() - t0
+        extra["planar_i420"] = dict(value=round(world * n * k3 / el3, 1), unit="frames/s", steps=k3, ms_per_step=round(1e3 * el3 / k3, 4),
+                                    payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
+                                    note="embed+detect on I420 planes (1.5 B/px in, 1.5 B/px out, conversion fused into the kernels); "
+                                         "payload read from the WRITTEN planes, i.e. after 4:2:0 subsampling")
+        del planes, pout
+
     if rank != 0:
         if world > 1:
             barrier()
             dist.destroy_process_group()
         return
+
+    # PCIe-inclusive rate (never `value`): frames start and end in pinned host memory, three-stream pipeline
+    if cfg == 2 and a.codec == "dct" and world == 1 and not a.no_extras and (H, W) == (1080, 1920):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pcie_pipeline
+            pc = {}
+            for fmt in ("rgb24", "i420"):
+                f_, g_ = pcie_pipeline.measure(fmt, n=200, B=50, H=H, W=W, eng=lanes[0]["eng"])
+                pc[fmt] = dict(frames_per_s=round(f_, 1), GBps_each_way=round(g_, 2))
+            extra["pcie_inclusive"] = dict(pc, note="embed+verify with every frame crossing PCIe in and out (pinned host memory, "
+                                                    "H2D / kernels / D2H on three streams); tools/pcie_pipeline.py")
+        except Exception as exc:
+            extra["pcie_inclusive"] = dict(error=repr(exc))
 
     # achievable HBM bandwidth of this device, same run: 16-byte streaming copy (read + write) and read-only stream
     if frames.numel() >= (1 << 28) and out is not None:
@@ -441,7 +482,8 @@ def main():
         # mark reads it again and writes the marked frame (6 B/px); the fused mark+verify kernel
         # moves the same 6 B/px and spares detect's 3 B/px read.  Sum over a step = 9 B/px.
         alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes, "svd": 2 * frame_bytes}
-        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>",
+        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel",
+                 "mark_fused": "embed_onepass_kernel" if a.onepass >= 0 else "mark_rgb8_kernel<fused verify>",
                  "svd": "svd_rgb8_kernel<embed+verify>"}
         ceiling = {"analyze": read_gbps, "mark": copy_gbps, "mark_fused": copy_gbps, "svd": copy_gbps}
         per = {}
@@ -506,7 +548,8 @@ def main():
         "config": {"workload": workload + f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} {op}+vote (BASELINE.json {what})",
                    "codec": a.codec, "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
                    "chunk_frames": chunk,
-                   "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")
+                   "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else
+                              "one-pass embed+verify kernel" if a.onepass >= 0 else "fused into the mark kernel")
                    if a.codec == "dct" else "fused into the embed kernel",
                    "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {world} rank(s), one RCCL all-gather of payloads"},
         "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,
