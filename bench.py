@@ -69,9 +69,6 @@ def parse():
     ap.add_argument("--separate-detect", action="store_true",
                     help="embed, then detect the written frames with the stand-alone detect kernels (analyze runs twice, "
                          "12 B/px of traffic) instead of the fused mark+verify kernel; same results bit for bit")
-    ap.add_argument("--onepass", type=int, default=-1, metavar="GRID",
-                    help="DCT codec: one-pass embed+verify (pixels stay in registers across the frame-mean dependency, 6 B/px of "
-                         "traffic); GRID = waves of the persistent kernel, 0 = what the device holds")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
                     help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
@@ -200,8 +197,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _hip.load()
-    flags = _hip.F_SEPARATE_DETECT if a.separate_detect else (_hip.F_ONEPASS if a.onepass >= 0 else 0)
-    op_grid = max(a.onepass, 0)
+    flags = _hip.F_SEPARATE_DETECT if a.separate_detect else 0
 
     # ---- workload ------------------------------------------------------------------------------------
     cfg = a.config
@@ -261,8 +257,8 @@ def main():
     n_chunks = max(1, (n + chunk - 1) // chunk)
     timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
     timing = None if a.no_kernel_events else _hip.Timing(6 * n_chunks * timed_steps + 16)
-    opts_plain = _hip.Opts(flags, op_grid, None)
-    opts_timed = timing.opts(flags, op_grid) if timing else opts_plain
+    opts_plain = _hip.Opts(flags, 0, None)
+    opts_timed = timing.opts(flags) if timing else opts_plain
     lanes = [dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain), out=out, stream=torch.cuda.current_stream())]
     if a.streams == 2:
         lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain),
@@ -482,8 +478,7 @@ def main():
         # mark reads it again and writes the marked frame (6 B/px); the fused mark+verify kernel
         # moves the same 6 B/px and spares detect's 3 B/px read.  Sum over a step = 9 B/px.
         alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes, "svd": 2 * frame_bytes}
-        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel",
-                 "mark_fused": "embed_onepass_kernel" if a.onepass >= 0 else "mark_rgb8_kernel<fused verify>",
+        names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>",
                  "svd": "svd_rgb8_kernel<embed+verify>"}
         ceiling = {"analyze": read_gbps, "mark": copy_gbps, "mark_fused": copy_gbps, "svd": copy_gbps}
         per = {}
@@ -548,8 +543,7 @@ def main():
         "config": {"workload": workload + f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} {op}+vote (BASELINE.json {what})",
                    "codec": a.codec, "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
                    "chunk_frames": chunk,
-                   "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else
-                              "one-pass embed+verify kernel" if a.onepass >= 0 else "fused into the mark kernel")
+                   "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")
                    if a.codec == "dct" else "fused into the embed kernel",
                    "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {world} rank(s), one RCCL all-gather of payloads"},
         "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,

@@ -49,24 +49,13 @@ const char *ofmk_last_error(void);
 typedef struct ofmk_timing ofmk_timing;     /* opaque, see ofmk_timing_create */
 typedef struct ofmk_opts {
     uint32_t flags;          /* OFMK_F_* */
-    uint32_t onepass_grid;   /* OFMK_F_ONEPASS: waves of the persistent kernel; 0 = what the device can hold (queried) */
+    uint32_t reserved;       /* must be 0 */
     ofmk_timing *timing;     /* NULL = launches carry no events */
 } ofmk_opts;
 /* ofmk_embed_detect_rgb8: embed, then detect the written frames with the stand-alone detect kernels
  * (analyze runs on the marked frames: 12 B/px of traffic) instead of the fused mark+verify kernel
  * (9 B/px).  Same results bit for bit. */
 #define OFMK_F_SEPARATE_DETECT 1u
-/* ofmk_embed_detect_rgb8: one pass over the pixels (6 B/px of traffic) instead of analyze + mark (9 B/px): a
- * persistent kernel keeps each block's pixels in registers while the frame-global mean the luminance mask needs
- * (dct_encoder.py:54-56) is completed by the other waves.  Same results bit for bit.  Used when every 64-block tile
- * of a frame can be in flight at once (ofmk_onepass_default_grid() >= ceil(blocks/64), < 4096 tiles per frame);
- * otherwise the call silently takes the two-kernel path.  Forward progress never depends on how many waves the
- * device actually runs: a wave whose wait for the mean times out hands its tile to a follow-up kernel. */
-#define OFMK_F_ONEPASS 2u
-/* Test hook for the one-pass kernel's recovery path: every third tile skips its wait (and is marked by the follow-up
- * kernel instead), and a grid smaller than a frame's tile count is accepted (so waits really time out). */
-#define OFMK_F_ONEPASS_TEST_GIVEUP 4u
-int ofmk_onepass_default_grid(void);   /* waves the device holds at once for the one-pass kernel (host query, no stream work) */
 
 /* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
  * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to

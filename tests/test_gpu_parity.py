@@ -775,53 +775,6 @@ def test_full_natural_1080p_frame(eng):
     assert abs((own != wm.reshape(-1)).mean() - (ref_bits != wm.reshape(-1)).mean()) < 1e-3
 
 
-def test_onepass_kernel_equals_two_kernel_path(eng):
-    """OFMK_F_ONEPASS: pixels stay in registers across the frame-mean dependency (6 instead of 9 B/px).  Must
-    reproduce analyze + fused mark bit for bit: marked frames, counts, raw bits -- for any grid size, frame size
-    (aligned or not, multiple of 8 or not), several chunks, per-frame watermark rows and in place."""
-    import torch
-    from offmark import _hip
-    from offmark.synthetic import synthetic_frames
-    lib = _hip.load()
-    cap = lib.ofmk_onepass_default_grid()
-    assert cap >= 256 * 8                                     # at least 2 waves per SIMD on every CU
-    for (H, W, n) in [(240, 320, 37), (1080, 1920, 30), (30, 44, 5), (64, 100, 3), (2160, 3840, 6)]:
-        N = H * W // 64
-        frames = synthetic_frames(n, H, W, seed=900 + H)
-        payloads = np.stack([[int(b) for b in format(s + 1, "08b")] for s in range(4)])
-        wm = np.stack([orc.shuffle_generate(p, (N,), 0) for p in payloads])
-        rows = (np.arange(n) % 4).astype(np.int32)
-        ref_out, ref_counts, ref_bits = eng.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
-        tpf = ((H // 8) * (W // 8) + 63) // 64
-        for grid, chunk in ((0, None), (tpf, None), (4 * tpf + 3, 2), (100000, None)):
-            e = type(eng)(opts=_hip.Opts(_hip.F_ONEPASS, grid, None), chunk_frames=chunk)
-            out, counts, bits = e.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
-            assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(bits, ref_bits), (H, W, grid)
-        inplace = frames.clone()
-        e = type(eng)(opts=_hip.Opts(_hip.F_ONEPASS, 0, None))
-        _, c2, _ = e.embed_detect(inplace, wm, L=8, wm_row=rows, out=inplace)
-        assert torch.equal(inplace, ref_out) and torch.equal(c2, ref_counts)
-
-
-def test_onepass_recovery_path(eng):
-    """A wave whose wait for the frame mean times out hands its tile to the follow-up kernel.  Exercised two ways:
-    the test hook makes every third tile skip its wait; and a grid SMALLER than a frame's tile count makes waits
-    time out for real (the frame cannot complete while its first waves hold their tiles).  Results must still be
-    bit-identical to the two-kernel path, and nothing may hang."""
-    import torch
-    from offmark import _hip
-    from offmark.synthetic import synthetic_frames
-    for (H, W, n, grid) in [(240, 320, 12, 0), (1080, 1920, 6, 0), (240, 320, 3, 8), (64, 100, 2, 1)]:
-        N = H * W // 64
-        frames = synthetic_frames(n, H, W, seed=950 + H)
-        wm = orc.shuffle_generate(P8, (1, N), 0)
-        ref = eng.embed_detect(frames, wm, L=8, want_bits=True)
-        e = type(eng)(opts=_hip.Opts(_hip.F_ONEPASS | _hip.F_ONEPASS_TEST_GIVEUP, grid, None))
-        got = e.embed_detect(frames, wm, L=8, want_bits=True)
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(got, ref)), (H, W, grid)
-
-
 def test_soft_decision_extension(eng):
     """Optional soft read-out (build extension): on clean frames it agrees with the hard decision
     and with a host evaluation of the same formula; under heavy noise, adding soft sums over the frames of a

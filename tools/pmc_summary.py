@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         k = r["Kernel_Name"]
         if "ofmk::" not in k:
             continue
-        name = ("onepass" if "onepass" in k else "redo" if "redo_kernel" in k else "analyze_yuv420" if "analyze_yuv420" in k
+        name = ("analyze_yuv420" if "analyze_yuv420" in k
                 else "mark_yuv420" if "mark_yuv420" in k else "analyze" if "analyze_kernel" in k
                 else "mark_fused" if "mark_rgb8_kernel<true, true" in k else "mark" if "mark_rgb8" in k
                 else "finalize" if "finalize" in k else "copy16" if "copy16" in k else "read16" if "read16" in k

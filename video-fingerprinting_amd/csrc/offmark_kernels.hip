@@ -41,7 +41,6 @@
 #include "svd_kernels.hiph"
 #include "misc_kernels.hiph"
 #include "planar_kernels.hiph"
-#include "onepass_kernels.hiph"
 
 namespace {
 
@@ -73,14 +72,12 @@ struct Ctx {
     hipStream_t s;
     ofmk_timing *t;
     unsigned flags;
-    int onepass_grid;
 };
 Ctx make_ctx(void *stream, const ofmk_opts *o) {
     Ctx c;
     c.s = static_cast<hipStream_t>(stream);
     c.t = o ? o->timing : nullptr;
     c.flags = o ? o->flags : 0u;
-    c.onepass_grid = o ? (int)o->onepass_grid : 0;
     return c;
 }
 
@@ -124,19 +121,15 @@ struct Workspace {
     float *delta;    // [frames][nblk]
     unsigned long long *ysum;    // mean accumulators of the frames analyze() saw
     unsigned long long *ysum2;   // ... of the marked frames (fused mark+verify kernel)
-    unsigned long long *op_ctl;  // one-pass kernel: ticket heads, then acc[frames], mean[frames]; then redo count + list
-    unsigned int *op_redo;       // [0] = count (own 256-byte line), list from op_redo + 64
     int frames;      // chunk capacity
     size_t plane;    // frames * nblk
 };
 
-constexpr size_t kFixedBytes = 8192;     // alignment slack of the carved arrays + the one-pass ticket heads and redo counter
-
-size_t tiles_per_frame(int H, int W) { return ((size_t)(H / 8) * (W / 8) + 63) / 64; }
+constexpr size_t kFixedBytes = 4096;     // alignment slack of the carved arrays
 
 size_t per_frame_bytes(int H, int W) {
     const size_t nblk = (size_t)(H / 8) * (W / 8);
-    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8 + (kHeads + 2) * 8 + tiles_per_frame(H, W) * sizeof(unsigned int);
+    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8;
 }
 
 int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out) {
@@ -158,10 +151,6 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     out.ysum = reinterpret_cast<unsigned long long *>(p);
     p += align256(cap * kSlots * 8);
     out.ysum2 = reinterpret_cast<unsigned long long *>(p);
-    p += align256(cap * kSlots * 8);
-    out.op_ctl = reinterpret_cast<unsigned long long *>(p);                 // heads | acc | mean: cleared by ONE memset
-    p += align256((kHeads * kHeadStride + (kHeads + 2) * cap) * 8);
-    out.op_redo = reinterpret_cast<unsigned int *>(p);                      // count (+ padding) | list
     return OFMK_OK;
 }
 
@@ -253,59 +242,6 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
         hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
-        HIP_TRY(hipGetLastError());
-    }
-    return OFMK_OK;
-}
-
-// One-pass embed + verify (onepass_kernels.hiph): leaves the marked frames in `out`, their records in ws.rec and their
-// mean accumulators in ws.ysum2 (as the fused mark kernel does), ready for finalize_detect(after_fused_mark).
-int onepass_grid(int requested) {
-    if (requested > 0) return requested;
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, embed_onepass_kernel<true>, 64, 0) != hipSuccess)
-        return 0;
-    return cus * per_cu;
-}
-
-int launch_onepass_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
-                        double alpha, const Workspace &ws, int grid, const Ctx &cx) {
-    const Geom g = make_geom(H, W, ws);
-    OnePassCtl ctl;
-    ctl.heads = ws.op_ctl;
-    ctl.acc = ws.op_ctl + kHeads * kHeadStride;
-    ctl.top = ctl.acc + (size_t)kHeads * ws.frames;
-    ctl.mean = ctl.top + ws.frames;
-    ctl.frames = ws.frames;
-    ctl.redo_count = ws.op_redo;
-    ctl.redo_list = ws.op_redo + 64;
-    ctl.tiles_per_frame = (int)tiles_per_frame(H, W);
-    ctl.total_tiles = ctl.tiles_per_frame * n;
-    ctl.test_giveup = (cx.flags & OFMK_F_ONEPASS_TEST_GIVEUP) ? 1 : 0;
-    HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, cx.s));
-    HIP_TRY(hipMemsetAsync(ws.op_ctl, 0, (size_t)(kHeads * kHeadStride + (kHeads + 2) * ws.frames) * 8, cx.s));
-    HIP_TRY(hipMemsetAsync(ws.op_redo, 0, 256, cx.s));
-    MarkArgs m;
-    m.rec = nullptr;
-    m.ysum = nullptr;
-    m.wm = wm;
-    m.wm_row = wm_row;
-    m.N = (int)((long long)H * W / 64);
-    m.alpha = alpha;
-    if (grid > ctl.total_tiles) grid = ctl.total_tiles;
-    const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
-    {
-        ScopedTiming timing(KIND_MARK_FUSED, cx);
-        if (al) OFMK_TIMED_LAUNCH(timing, embed_onepass_kernel<true>, dim3((unsigned)grid), dim3(64), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2, ctl);
-        else OFMK_TIMED_LAUNCH(timing, embed_onepass_kernel<false>, dim3((unsigned)grid), dim3(64), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2, ctl);
-    }
-    const int rgrid = ctl.total_tiles < 2048 ? ctl.total_tiles : 2048;       // normally finds an empty list and exits
-    if (al) hipLaunchKernelGGL(redo_kernel<true>, dim3((unsigned)rgrid), dim3(64), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2, ctl);
-    else hipLaunchKernelGGL(redo_kernel<false>, dim3((unsigned)rgrid), dim3(64), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2, ctl);
-    HIP_TRY(hipGetLastError());
-    if (in != out && (H % 8 || W % 8)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, cx.s, in, out, n, H, W);
         HIP_TRY(hipGetLastError());
     }
     return OFMK_OK;
@@ -569,22 +505,9 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
     const Ctx cx = make_ctx(stream, opts);
-    // one-pass: every tile of a frame should be able to be in flight at once (else waves time out and the redo
-    // kernel does their work: correct, but slower than the two-kernel path), and the arrival count must fit
-    int op_grid = 0;
-    if ((cx.flags & OFMK_F_ONEPASS) && !(cx.flags & OFMK_F_SEPARATE_DETECT)) {
-        op_grid = onepass_grid(cx.onepass_grid);
-        const size_t tpf = tiles_per_frame(H, W);
-        if (tpf >= (1u << kCountBits) || ((size_t)op_grid < tpf && !(cx.flags & OFMK_F_ONEPASS_TEST_GIVEUP))) op_grid = 0;
-    }
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if (op_grid > 0) {
-            const size_t fo = (size_t)f0 * H * W * 3;
-            if (counts) HIP_TRY(hipMemsetAsync(counts + (size_t)f0 * L, 0, (size_t)cf * L * sizeof(int32_t), cx.s));
-            if ((rc = launch_onepass_rgb8(in + fo, out + fo, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, op_grid, cx))) return rc;
-            if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, cx))) return rc;
-        } else if (!(cx.flags & OFMK_F_SEPARATE_DETECT)) {
+        if (!(cx.flags & OFMK_F_SEPARATE_DETECT)) {
             if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, cx, counts, L))) return rc;
             if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, cx))) return rc;
         } else {
@@ -859,8 +782,6 @@ int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
-
-int ofmk_onepass_default_grid(void) { return onepass_grid(0); }
 
 // ---- timing objects (caller-owned; see the header) ------------------------------------------------
 int ofmk_timing_create(int max_launches, unsigned kind_mask, ofmk_timing **out) {

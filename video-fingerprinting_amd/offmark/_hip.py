@@ -17,12 +17,10 @@ ABI_VERSION = 2
 
 class Opts(C.Structure):
     """ofmk_opts: per-call options (flags, optional timing object).  None / NULL = defaults."""
-    _fields_ = [("flags", C.c_uint32), ("onepass_grid", C.c_uint32), ("timing", C.c_void_p)]
+    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_uint32), ("timing", C.c_void_p)]
 
 
 F_SEPARATE_DETECT = 1
-F_ONEPASS = 2
-F_ONEPASS_TEST_GIVEUP = 4
 YUV_I420, YUV_NV12 = 0, 1
 TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar")
 
@@ -57,7 +55,6 @@ SIGNATURES = {
                                         _sz, _vp, _op]),
     "ofmk_yuv420_to_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ofmk_rgb8_to_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "ofmk_onepass_default_grid": (_i32, []),
     "ofmk_hbm_copy": (_i32, [_vp, _vp, _sz, _vp]),
     "ofmk_hbm_read": (_i32, [_vp, _sz, _vp, _vp]),
     "ofmk_timing_create": (_i32, [_i32, _u32, C.POINTER(_vp)]),
@@ -109,8 +106,8 @@ class Timing:
         self.handle = _vp()
         check(self.lib.ofmk_timing_create(int(max_launches), int(kind_mask), C.byref(self.handle)))
 
-    def opts(self, flags: int = 0, onepass_grid: int = 0) -> Opts:
-        return Opts(flags, onepass_grid, self.handle)
+    def opts(self, flags: int = 0) -> Opts:
+        return Opts(flags, 0, self.handle)
 
     def collect(self) -> dict:
         ms = (_f64 * len(TIMING_KINDS))()
