@@ -979,3 +979,50 @@ def test_bench_dry_run_of_the_collective_path():
         assert key in line
     assert line["payload_bit_exact"] and line["n_gpus"] == 1 and line["steps"] == 3
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0
+
+
+@pytest.mark.parametrize("config,extra", [(4, []), (5, []), (3, ["--frames", "6", "--chunk", "4"]), (2, ["--frames", "24"])])
+def test_bench_configs_run_at_one_gpu(config, extra):
+    """bench.py --config 2/3/4/5 (BASELINE.json configs[1..4]) at N=1, shortened: the line keeps its contract, the
+    payloads / votes / leak copy sequence check out, and the extras of the default config are present."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    small = ["--height", "240", "--width", "320"] if config != 2 else []
+    if config in (4, 5):
+        small += ["--frames", "6"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", str(config), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", *small, *extra], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["payload_bit_exact"] and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["scaling"] == ("strong" if config in (4, 5) else "weak")
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert line["hbm_copy_GBps"] > 3000 and line["hbm_read_GBps"] > 3000
+    if config == 2:
+        assert line["value_separate_detect"] > 0 and line["separate_detect"]["votes_ok"]
+        assert line["planar_i420"]["payload_ok"] and line["planar_i420"]["value"] > 0
+        assert line["pcie_inclusive"]["i420"]["frames_per_s"] > line["pcie_inclusive"]["rgb24"]["frames_per_s"] > 0
+
+
+@pytest.mark.parametrize("config", [4, 2])
+def test_bench_two_ranks_gloo_on_one_device(config):
+    """The N>1 flow of bench.py (sharding of segments / frames over ranks, all-gather of the payloads, vote on every
+    rank, MAX over ranks) with two processes on the one GPU of the box, gloo standing in for RCCL (a one-GPU box cannot
+    run RCCL across ranks)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--config", str(config), "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["payload_bit_exact"]
+    assert line["config"]["frames_per_gpu"] == (8 if config == 2 else 4 * 8)      # config 4: 8 segments / 2 ranks x 8 frames
