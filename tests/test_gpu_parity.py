@@ -140,7 +140,7 @@ def test_golden_embed_and_detect(eng, case):
     _, bits_own = eng.detect(cuda(marked[None]), L, alpha=alpha, want_bits=True)
     det = mask[: (H // 8) * 8: 8, : (W // 8) * 8: 8].reshape(-1)
     assert_bits_close(bits_own[0].cpu().numpy()[:nblk][det], g["raw_bits"].reshape(-1)[:nblk][det], nblk)
-    # detect the reference's own marked frame: isolates the detect path
+    # detect the golden vector's marked frame (the reference's logic over the restated cv2 primitives): isolates the detect path
     counts, bits = eng.detect(cuda(g["marked"][None]), L, alpha=alpha, want_bits=True)
     bits = bits[0].cpu().numpy()
     assert bits.shape == (N,)

@@ -1,6 +1,12 @@
-"""Pins oracle/offmark_oracle.py against vectors captured from the reference's own modules
-(tools/make_golden.py).  CPU only.  Bit-exact in ``promotion="nep50"`` mode, which is how the
-reference code evaluates under the numpy 2.x that generated the vectors."""
+"""Pins oracle/offmark_oracle.py against vectors captured by running the reference's own modules in the build
+container (tools/make_golden.py).  CPU only.  Bit-exact in ``promotion="nep50"`` mode, which is how the
+reference code evaluates under the numpy 2.x that generated the vectors.
+
+What these vectors pin: the numpy-only modules (shuffler, grayscale, de_shuffler, de_grayscale) ran unmodified, so
+their vectors are reference outputs.  dct_encoder / dct_decoder / video.embedder / dwt_dct_svd_* import cv2 and pywt,
+which are not installed: they ran with tools/standins/ supplying dct / idct / cvtColor / dwt2 / idwt2 FROM THIS
+ORACLE'S OWN RESTATED PRIMITIVES.  Those vectors pin the reference's control flow, scalar semantics and numpy
+promotion, not OpenCV's or PyWavelets' float rounding: PARITY UNPINNED (OpenCV / pywt arithmetic)."""
 import os
 
 import numpy as np
@@ -146,7 +152,7 @@ from conftest import svd_golden_cases  # noqa: E402
 
 @pytest.mark.parametrize("form", ["vec", "loop"])
 @pytest.mark.parametrize("case", svd_golden_cases())
-def test_svd_codec_bit_exact_against_reference(case, form):
+def test_svd_codec_bit_exact_against_reference_logic_vectors(case, form):
     g = load(case)
     if form == "loop" and g["frame"].shape[0] > 128:
         pytest.skip("loop form only on small frames")
@@ -206,7 +212,7 @@ def test_grayscale_numbers_payload_at_scale(tag, h, w):
         assert np.array_equal(GrayScale(key=key).generate_wm(img, cap), wm)
     assert bool(caught) == bool(g[tag + "_warned"]) == (img.size > cap[1])
     # the digests were captured under this container's numpy 2 (NEP 50 promotion inside texture_mask), like every
-    # other reference-run vector: the oracle reproduces them with promotion="nep50" 
+    # other vector captured by running the reference's modules here: the oracle reproduces them with promotion="nep50" 
     enc = orc.DctEncoderOracle(alpha=alpha, promotion="nep50")
     enc.read_wm(wm)
     marked = orc.mark_frame(frame, enc)
