@@ -48,8 +48,8 @@ const char *ofmk_last_error(void);
  * src/offmark/embed/dct_encoder.py:6-16; this is the same idea at the C boundary).  Pass NULL for defaults. */
 typedef struct ofmk_timing ofmk_timing;     /* opaque, see ofmk_timing_create */
 typedef struct ofmk_opts {
-    uint32_t flags;          /* OFMK_F_* */
-    uint32_t reserved;       /* must be 0 */
+    uint32_t flags;          /* OFMK_F_*; unknown bits are rejected (OFMK_E_ARG) */
+    uint32_t reserved;       /* must be 0 (rejected otherwise) */
     ofmk_timing *timing;     /* NULL = launches carry no events */
 } ofmk_opts;
 /* ofmk_embed_detect_rgb8: embed, then detect the written frames with the stand-alone detect kernels

@@ -141,3 +141,30 @@ def test_planar_argument_checks(eng):
     assert lib.ofmk_yuv420_to_rgb8(None, buf.data_ptr(), 0, 1, 16, 16, s) == -1
     with pytest.raises(ValueError):
         eng.embed_yuv420(buf[: 16 * 16 * 3 // 2].view(1, -1)[:, :-8], 16, 16, np.zeros((1, 4)))
+
+
+def test_plugin_classes_on_planes(eng):
+    """DctEncoder / DctDecoder convenience entries for planar frames, and the opts validation of the C ABI."""
+    import torch
+    from offmark import _hip
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.embed.dct_encoder import DctEncoder
+    from offmark.extract.dct_decoder import DctDecoder
+    from offmark.generator.shuffler import Shuffler
+    from offmark.synthetic import synthetic_frames
+    H, W, n = 240, 320, 5
+    planes = eng.rgb_to_yuv420(synthetic_frames(n, H, W, seed=41), "nv12")
+    enc = DctEncoder(alpha=20)
+    enc.read_wm(Shuffler(key=0).generate_wm(P8, enc.wm_capacity((H, W, 3))))
+    marked = enc.encode_planes_yuv420(planes, H, W, layout="nv12")
+    assert torch.equal(marked, eng.embed_yuv420(planes, H, W, enc.wm[None], layout="nv12"))
+    counts, _ = DctDecoder(alpha=20).decode_planes_yuv420(marked, H, W, 8, layout="nv12")
+    got = DeShuffler(key=0).set_shape((8,)).degenerate_counts(counts.cpu().numpy(), H * W // 64)
+    assert np.array_equal(got, np.tile(P8, (n, 1)))
+    lib = _hip.load()
+    ws = eng.workspace(H, W, n)
+    bad = _hip.Opts(8, 0, None)
+    wm = torch.zeros(H * W // 64, dtype=torch.uint8, device="cuda")
+    assert lib.ofmk_embed_yuv420(planes.data_ptr(), marked.data_ptr(), 1, n, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(),
+                                 ws.numel(), _hip.current_stream(), bad) == -1
+    assert b"ofmk_opts" in lib.ofmk_last_error()

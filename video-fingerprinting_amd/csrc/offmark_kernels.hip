@@ -154,6 +154,13 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     return OFMK_OK;
 }
 
+// every entry point that takes ofmk_opts: unknown flag bits or a non-zero reserved word are a caller bug, not a default
+int check_opts(const ofmk_opts *o) {
+    if (o && ((o->flags & ~(uint32_t)OFMK_F_SEPARATE_DETECT) || o->reserved))
+        return fail(OFMK_E_ARG, "ofmk_opts: unknown flag bits or non-zero reserved field%s");
+    return OFMK_OK;
+}
+
 int check_dims(int n, int H, int W) {
     if (n <= 0) return fail(OFMK_E_ARG, "n must be positive%s");
     if (H < 8 || W < 8) return fail(OFMK_E_ARG, "H and W must be at least 8%s");
@@ -444,6 +451,7 @@ size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W) {
 int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                     const int32_t *wm_row, double alpha, int chunk_frames, void *workspace, size_t workspace_bytes,
                     void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     Workspace ws;
@@ -458,6 +466,7 @@ int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const 
 
 int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
                      int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
     Workspace ws;
@@ -499,6 +508,7 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
                            const int32_t *wm_row, double alpha, int L, int32_t *counts, uint8_t *bits,
                            int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
                            const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
@@ -570,6 +580,7 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
 
 int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W, void *workspace, size_t workspace_bytes,
                             void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!in) return fail(OFMK_E_ARG, "null frame pointer%s");
@@ -581,6 +592,7 @@ int ofmk_stage_analyze_rgb8(const uint8_t *in, int n, int H, int W, void *worksp
 
 int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, double alpha,
                          int fused, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, 1);
     if (rc) return rc;
     Workspace ws;
@@ -591,6 +603,7 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, c
 
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                         const int32_t *wm_row, const double *scales, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     SvdArgs a;
@@ -603,6 +616,7 @@ int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, co
 // scales[1] <= 0: the reference's decoder returns channel 1's (never written) bit array: all zeros
 int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales, int32_t *counts, uint8_t *bits,
                          void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
     SvdArgs a;
@@ -621,6 +635,7 @@ int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const do
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
                                const int32_t *wm_row, const double *scales, int L, int32_t *counts, uint8_t *bits,
                                void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
@@ -683,6 +698,7 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
 int ofmk_embed_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, int n_wm,
                       const int32_t *wm_row, double alpha, int chunk_frames, void *workspace, size_t workspace_bytes,
                       void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_planar(layout, H, W, in, out))) return rc;
@@ -701,6 +717,7 @@ int ofmk_embed_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H,
 
 int ofmk_detect_yuv420(const uint8_t *in, int layout, int n, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
                        int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
     if ((rc = check_planar(layout, H, W, in, nullptr))) return rc;
@@ -719,6 +736,7 @@ int ofmk_detect_yuv420(const uint8_t *in, int layout, int n, int H, int W, int L
 int ofmk_embed_detect_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, int n_wm,
                              const int32_t *wm_row, double alpha, int L, int32_t *counts, uint8_t *bits, int chunk_frames,
                              void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;

@@ -75,3 +75,10 @@ class DctEncoder:
         n, h, w, _ = frames.shape
         wm = wm_table if wm_table is not None else self._device_wm(h * w // 64)
         return self.engine.embed(frames, wm, alpha=self.alpha, wm_row=wm_rows, out=out)
+
+    def encode_planes_yuv420(self, planes, height, width, out=None, wm_rows=None, wm_table=None, layout="i420"):
+        """planes: CUDA uint8 [n, 1.5*H*W] (I420: Y|U|V per frame, NV12: Y|UV): the frame step on what a decoder produces
+        and an encoder takes (reference: ffmpeg's rgb24 pipe and yuv420p writer, frame_reader.py:42-64, frame_writer.py:33-34),
+        with the build-defined BT.601 conversion fused into the kernels.  Returns marked planes of the same layout."""
+        wm = wm_table if wm_table is not None else self._device_wm(height * width // 64)
+        return self.engine.embed_yuv420(planes, height, width, wm, alpha=self.alpha, wm_row=wm_rows, out=out, layout=layout)

@@ -43,3 +43,7 @@ class DctDecoder:
     def decode_frames_u8(self, frames, payload_len, want_bits=False):
         """frames: CUDA uint8 [n, H, W, 3] -> (counts int32 [n, L] on device, bits or None)."""
         return self.engine.detect(frames, payload_len, alpha=self.alpha, want_bits=want_bits)
+
+    def decode_planes_yuv420(self, planes, height, width, payload_len, want_bits=False, layout="i420"):
+        """planes: CUDA uint8 [n, 1.5*H*W] (I420 or NV12) -> (counts int32 [n, L] on device, bits or None)."""
+        return self.engine.detect_yuv420(planes, height, width, payload_len, alpha=self.alpha, want_bits=want_bits, layout=layout)
