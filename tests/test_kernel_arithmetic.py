@@ -83,3 +83,24 @@ def test_scaled_dct_flow_graph_reproduces_the_orthonormal_dct():
     assert rel(tot - dcl, eh_o).max() <= 1e-6 and rel(dcl, dcl_o).max() <= 1e-6 and rel(e, e_o).max() <= 1e-6
     # no systematic bias (a mistyped constant shows up here first): mean signed relative error of eh
     assert abs(((tot - dcl).astype(np.float64) - eh_o).mean() / eh_o.mean()) <= 1e-7
+
+
+def test_texture_thresholds_are_the_float32_images_of_the_float64_comparisons():
+    """texture_mask compares float32 ratios with python floats, i.e. in float64 under the reference's numpy 1.23
+    (dct_encoder.py:92-101).  The kernel compares in float32 against TA1/TB1/TA2/TB2 = the smallest float32 not below
+    2.3 / 1.6 / 1.4 / 1.1: the same decision for every float32 input, nan and inf included."""
+    for name, t in (("TA1", 2.3), ("TB1", 1.6), ("TA2", 1.4), ("TB2", 1.1)):
+        m = re.search(r"\b" + name + r"\s*=\s*(0x[0-9a-fA-F.]+p[+-]?[0-9]+)f", SRC)
+        assert m, name
+        T = F(float.fromhex(m.group(1)))
+        assert float(T) == float.fromhex(m.group(1))                       # the literal is a float32
+        assert float(T) >= t > float(np.nextafter(T, F(-np.inf)))           # smallest float32 not below t
+        x = T
+        for _ in range(2000):                                               # 2000 float32 neighbours on each side
+            x = np.nextafter(x, F(-np.inf))
+        for _ in range(4000):
+            assert (np.float64(x) >= t) == bool(x >= T)
+            x = np.nextafter(x, F(np.inf))
+        for special in (F(np.inf), F(-np.inf), F(np.nan), F(0), F(1e30)):
+            with np.errstate(invalid="ignore"):
+                assert (np.float64(special) >= t) == bool(special >= T)
