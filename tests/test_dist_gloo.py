@@ -71,3 +71,45 @@ def test_ragged_shards_all_gather_and_vote():
 
 def test_four_ranks_ragged():
     _run(50, ragged=True, world=4)
+
+
+def test_eight_ranks_one_segment_each_config4_shape():
+    """BASELINE config 4 at its full width: 8 segments x 48 frames, segment s on rank s (equal shards), payload
+    format(s + 1, '08b'); every rank must end with every segment's payload (tests/segment_mark_detect_hls.py:126-155)."""
+    n_total = 8 * 48
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, n_total, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=240) for _ in range(8))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(out[r] == out[0] for r in range(8))
+    assert sorted(out[0]) == list(range(8))
+    for seg, (pattern, freq) in out[0].items():
+        assert pattern == [int(b) for b in format(seg + 1, "08b")] and freq >= 0.5
+
+
+def _worker8(rank, world, port, n_total, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.join(os.path.dirname(here), "video-fingerprinting_amd")]
+    from offmark.dist.vote import gather_payloads, shard_range, vote_segments
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per = n_total // world
+        assert shard_range(n_total, rank, world) == (rank * per, (rank + 1) * per)     # segment s -> rank s
+        rng = np.random.default_rng(100 + rank)               # each rank only ever sees its own segment
+        mine = np.tile(np.array([int(b) for b in format(rank + 1, "08b")], dtype=np.uint8), (per, 1))
+        flip = rng.random(per) < 0.25
+        mine[flip] ^= rng.integers(0, 2, size=(int(flip.sum()), 8)).astype(np.uint8)
+        everyone = gather_payloads(torch.from_numpy(mine), equal_shards=True).numpy()
+        assert everyone.shape == (n_total, 8) and np.array_equal(everyone[rank * per:(rank + 1) * per], mine)
+        votes = vote_segments(everyone, np.repeat(np.arange(world), per))
+        q.put((rank, {int(k): (v[0].tolist(), v[1]) for k, v in votes.items()}))
+    finally:
+        dist.destroy_process_group()
