@@ -1018,8 +1018,12 @@ def test_bench_two_ranks_gloo_on_one_device(config):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    import socket
+    with socket.socket() as sock:                  # a port that is free now (the two parametrised runs follow each other)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
            "--config", str(config), "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline", "--no-extras"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
