@@ -104,3 +104,145 @@ def test_texture_thresholds_are_the_float32_images_of_the_float64_comparisons():
         for special in (F(np.inf), F(-np.inf), F(np.nan), F(0), F(1e30)):
             with np.errstate(invalid="ignore"):
                 assert (np.float64(special) >= t) == bool(special >= T)
+
+
+# ---- DwtDctSvd: top singular value by Householder tridiagonalisation + Laguerre (svd_kernels.hiph) ----------------
+def _svd_gram(B):
+    G = np.zeros(B.shape[:1] + (4, 4), F)
+    for i in range(4):
+        for j in range(i, 4):
+            acc = B[:, 0, i] * B[:, 0, j]
+            for k in range(1, 4):
+                acc = fma(B[:, k, i], B[:, k, j], acc)
+            G[:, i, j] = acc
+    return G
+
+
+def _svd_top_eigenvalue(G, tol, cap):
+    """gram_top_eigenvalue() line by line in float32 (fma = exact product, one rounding)."""
+    tiny = F(1e-30)
+    x0, x1, x2 = G[:, 0, 1], G[:, 0, 2], G[:, 0, 3]
+    tail = fma(x2, x2, x1 * x1)
+    n2 = fma(x0, x0, tail)
+    nb1 = np.sqrt(n2)
+    v0 = x0 + np.copysign(nb1, x0)
+    vtv = fma(v0, v0, tail)
+    with np.errstate(all="ignore"):
+        beta = np.where(tail > tiny, F(2) / vtv, F(0)).astype(F)
+    s00, s01, s02, s11, s12, s22 = (G[:, 1, 1].copy(), G[:, 1, 2].copy(), G[:, 1, 3].copy(), G[:, 2, 2].copy(), G[:, 2, 3].copy(),
+                                    G[:, 3, 3].copy())
+    p0 = beta * fma(s02, x2, fma(s01, x1, s00 * v0))
+    p1 = beta * fma(s12, x2, fma(s11, x1, s01 * v0))
+    p2 = beta * fma(s22, x2, fma(s12, x1, s02 * v0))
+    K = F(0.5) * beta * fma(x2, p2, fma(x1, p1, v0 * p0))
+    q0, q1, q2 = fma(-K, v0, p0), fma(-K, x1, p1), fma(-K, x2, p2)
+    s00 = fma(F(-2) * v0, q0, s00)
+    s01 = fma(-q0, x1, fma(-v0, q1, s01))
+    s02 = fma(-q0, x2, fma(-v0, q2, s02))
+    s11 = fma(F(-2) * x1, q1, s11)
+    s12 = fma(-q1, x2, fma(-x1, q2, s12))
+    s22 = fma(F(-2) * x2, q2, s22)
+    tail2 = s02 * s02
+    m2 = fma(s01, s01, tail2)
+    nb2 = np.sqrt(m2)
+    w0 = s01 + np.copysign(nb2, s01)
+    wtw = fma(w0, w0, tail2)
+    with np.errstate(all="ignore"):
+        beta2 = np.where(tail2 > tiny, F(2) / wtw, F(0)).astype(F)
+    p0 = beta2 * fma(s12, s02, s11 * w0)
+    p1 = beta2 * fma(s22, s02, s12 * w0)
+    K = F(0.5) * beta2 * fma(s02, p1, w0 * p0)
+    q0, q1 = fma(-K, w0, p0), fma(-K, s02, p1)
+    s11 = fma(F(-2) * w0, q0, s11)
+    s12 = fma(-q0, s02, fma(-w0, q1, s12))
+    s22 = fma(F(-2) * s02, q1, s22)
+    a0, a1, a2, a3 = G[:, 0, 0], s00, s11, s22
+    b1q, b2q, b3q, nb3 = n2, m2, s12 * s12, np.abs(s12)
+    gersh = np.maximum(np.maximum(a0 + nb1, a1 + nb1 + nb2), np.maximum(a2 + nb2 + nb3, a3 + nb3))
+    lam = np.minimum(gersh, (a0 + a1) + (a2 + a3)).astype(F)
+    active = np.ones(len(lam), bool)
+    iters = np.zeros(len(lam), int)
+    for _ in range(cap):
+        d0, d1, d2, d3 = a0 - lam, a1 - lam, a2 - lam, a3 - lam
+        p1 = d0
+        p2, e2 = fma(d1, p1, -b1q), -d1 - p1
+        p3, e3, f3 = fma(d2, p2, -b2q * p1), fma(d2, e2, b2q - p2), fma(d2, F(2), F(-2) * e2)
+        p4, e4, f4 = fma(d3, p3, -b3q * p2), fma(d3, e3, fma(-b3q, e2, -p3)), fma(d3, f3, fma(F(-2), e3, F(-2) * b3q))
+        with np.errstate(all="ignore"):
+            rp = (F(1) / p4).astype(F)
+            g = e4 * rp
+            h = fma(g, g, -f4 * rp)
+            t = np.maximum(F(3) * fma(F(4), h, -g * g), F(0))
+            step = (F(4) / (g + np.copysign(np.sqrt(t), g))).astype(F)
+            step = np.where((p4 != 0) & (np.abs(step) < F(3.0e38)), step, F(0)).astype(F)
+        lam = np.where(active, lam - step, lam).astype(F)
+        iters += active
+        active &= np.abs(step) > tol * np.abs(lam)
+        if not active.any():
+            break
+    return np.maximum(lam, F(0)), iters
+
+
+def test_svd_top_value_solver_float32_replay():
+    """The DwtDctSvd kernels take the top singular value of each 4x4 LL block from the Gram matrix by two Householder
+    reflections and Laguerre's iteration on the tridiagonal form (svd_kernels.hiph: gram_top_eigenvalue).  Replayed here
+    in float32 against float64 LAPACK (np.linalg.svd is what the reference calls, dwt_dct_svd_encoder.py:41) with the
+    tolerances and iteration caps the kernel source passes: well separated, repeated, nearly repeated, rank-1 and zero
+    spectra, LL-like magnitudes."""
+    src = open(os.path.join(PKG, "csrc", "svd_kernels.hiph")).read()
+    calls = re.findall(r"gram_top_eigenvalue\(G,\s*([0-9.eE+-]+)f,\s*(\d+)\)", src)
+    assert len(calls) == 2, calls
+    (tol_read, cap_read), (tol_embed, cap_embed) = sorted(((float(t), int(c)) for t, c in calls), reverse=True)
+    rng = np.random.default_rng(5)
+    sets = [rng.uniform(-200, 200, (6000, 4, 4)), rng.uniform(0, 510, (6000, 4, 4)), 1 + rng.normal(0, 1, (6000, 4, 4)),
+            np.ones((1, 4, 4)) * rng.uniform(0, 300, (2000, 1, 1)) + rng.normal(0, 0.3, (2000, 4, 4))]     # near-flat LL blocks
+    adv = [np.zeros((4, 4)), np.ones((4, 4)), np.eye(4) * 7, np.diag([5., 5, 1, 0]), np.diag([3., 3, 3, 3.0000001]),
+           np.diag([100., 99.9999, 1e-3, 0]), np.outer([1., 2, 3, 4], [4., 3, 2, 1]), np.diag([0., 0, 0, 9]), np.diag([1e-3, 0, 0, 0])]
+    for k in range(400):
+        q1, _ = np.linalg.qr(rng.normal(size=(4, 4)))
+        q2, _ = np.linalg.qr(rng.normal(size=(4, 4)))
+        s = np.sort(rng.uniform(0, 1000, 4))[::-1]
+        if k % 4 == 0:
+            s[1] = s[0]
+        elif k % 4 == 1:
+            s[1] = s[0] * (1 - 1e-5)
+        elif k % 4 == 2:
+            s[1:] = 0
+        adv.append(q1 @ np.diag(s) @ q2.T)
+    B = np.concatenate(sets + [np.array(adv)]).astype(F)
+    ref = np.linalg.svd(B.astype(np.float64), compute_uv=False)[:, 0]
+    G = _svd_gram(B)
+    big = ref > 1e-3
+    lam, iters = _svd_top_eigenvalue(G, F(tol_embed), cap_embed)
+    rel = np.abs(np.sqrt(lam.astype(np.float64)) - ref) / np.maximum(ref, 1e-30)
+    assert rel[big].max() <= 6e-7, rel[big].max()                          # measured 4.6e-7; embed then refines with |B v0|
+    assert np.abs(np.sqrt(lam.astype(np.float64)) - ref)[~big].max() <= 1e-3
+    assert iters.max() <= cap_embed and iters.mean() <= 3.0                # cubic convergence except for repeated roots
+    lam, iters = _svd_top_eigenvalue(G, F(tol_read), cap_read)
+    rel = np.abs(np.sqrt(lam.astype(np.float64)) - ref) / np.maximum(ref, 1e-30)
+    # read-out: bit = (s0 mod scale) > scale/2, margin scale/4 >= 1.9 for any scale >= 7.5; s0 <= 2040 for u8 frames
+    assert rel[big].max() <= 1e-4 and rel[big].max() * 2040 < 0.25, rel[big].max()
+
+
+def test_fmod_shortcut_is_fmod():
+    """fmod_pos (svd_kernels.hiph): trunc of an inflated quotient estimate, one fma, one fix-up == fmodf, bit for bit, for
+    0 <= a < 2^20 * b.  Replayed in float32 with a 1-ulp-wrong reciprocal in both directions (v_rcp_f32 is accurate to 1 ulp)."""
+    src = open(os.path.join(PKG, "csrc", "svd_kernels.hiph")).read()
+    m = re.search(r"__builtin_amdgcn_rcpf\(b\) \* ([0-9.]+)f\)", src)
+    infl = F(float(m.group(1)))
+    assert float(infl) > 1 + 3 * 2.0 ** -23                      # more than rcp's ulp plus two roundings
+    rng = np.random.default_rng(9)
+    b = np.concatenate([rng.uniform(0.5, 60, 200000), np.full(50000, 15.0), np.full(50000, 36.0)]).astype(F)
+    a = (rng.uniform(0, 2100, b.size)).astype(F)
+    n = rng.integers(0, 60, 60000)
+    a[:60000] = (n * b[:60000].astype(np.float64)).astype(F)     # exact and nearly exact multiples
+    a[60000:90000] = np.nextafter(a[:30000], F(np.inf))
+    a[90000:120000] = np.nextafter(a[:30000], F(-np.inf)).clip(0)
+    want = np.fmod(a, b)
+    for wrong in (0, 1, -1):
+        rcp = (F(1) / b).astype(F)
+        rcp = np.nextafter(rcp, F(np.inf)) if wrong > 0 else np.nextafter(rcp, F(0)) if wrong < 0 else rcp
+        q = np.trunc(((a * rcp).astype(F) * infl).astype(F))
+        r = fma(-q, b, a)
+        r = np.where(r < 0, r + b, r).astype(F)
+        assert np.array_equal(r, want), (wrong, np.flatnonzero(r != want)[:5])
