@@ -1000,10 +1000,12 @@ def test_bench_configs_run_at_one_gpu(config, extra):
     assert line["payload_bit_exact"] and line["n_gpus"] == 1 and line["value"] > 0
     assert line["scaling"] == ("strong" if config in (4, 5) else "weak")
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"]
     assert line["hbm_copy_GBps"] > 1000 and line["hbm_read_GBps"] > 1000      # sanity only: a rate, not a ranking
     if config == 2:
         assert line["value_separate_detect"] > 0 and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["planar_i420"]["value"] > 0
+        assert line["dwtdctsvd"]["payload_ok"] and line["dwtdctsvd"]["value"] > 0
         # both rates are reported, not ranked: the PCIe leg shares the host with whatever else runs on the box
         assert line["pcie_inclusive"]["i420"]["frames_per_s"] > 0 and line["pcie_inclusive"]["rgb24"]["frames_per_s"] > 0
 
