@@ -198,8 +198,13 @@ int launch_analyze(const void *frames, int src, int n, int H, int W, const Works
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
     ScopedTiming timing(KIND_ANALYZE, cx);
     if (src == SRC_RGB8) {
-        if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
-        else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
+        // Occupancy cap by an (unused) dynamic LDS reservation: 48 KiB per workgroup = 3 workgroups per CU instead of the
+        // 5 the registers allow.  Measured on the shipped kernel, interleaved in one session (profiles/r2_tuning_sweep.txt):
+        // 3 per CU 0.341 ms, 4 or 5 per CU 0.350, 2 per CU 0.367, 1 per CU 0.553 -- fewer resident wavefronts keep the
+        // window of frame bytes in flight smaller, which the memory system rewards (the bare read pattern shows the same).
+        constexpr unsigned kAnalyzeLdsCap = 48u * 1024u;
+        if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, true>), grid, dim3(kThreads), kAnalyzeLdsCap, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
+        else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_RGB8, false>), grid, dim3(kThreads), kAnalyzeLdsCap, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
     } else {
         if (al) OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_YUV32F, true>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
         else OFMK_TIMED_LAUNCH(timing, (analyze_kernel<SRC_YUV32F, false>), grid, dim3(kThreads), 0, s, frames, g, ws.rec, ws.ysum, zero_counts, L);
