@@ -337,7 +337,7 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
         if (b.bits) b.bits += (size_t)f0 * a.N;
         const dim3 grid = block_grid(g, cf);
         ScopedTiming timing(KIND_SVD, cx);
-#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
+#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), OFMK_SVD_LDS_CAP, s, in + fo, out ? out + fo : nullptr, g, b)
         const bool multi = a.scales[0] > 0.f || a.scales[2] > 0.f || !(a.scales[1] > 0.f);      // anything but the default [0, s, 0]
         if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT, false); else OFMK_SVD_LAUNCH(false, SVD_DETECT, false); }
         else if (mode == SVD_EMBED && !multi) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED, false); else OFMK_SVD_LAUNCH(false, SVD_EMBED, false); }
