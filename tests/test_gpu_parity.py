@@ -1027,9 +1027,12 @@ def test_bench_two_ranks_gloo_on_one_device(config):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
            "--config", str(config), "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-extras"]
+           "--no-cpu-baseline"] + (["--no-extras"] if config != 2 else [])      # config 2: the side measurements run on every rank too
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["payload_bit_exact"]
     assert line["config"]["frames_per_gpu"] == (8 if config == 2 else 4 * 8)      # config 4: 8 segments / 2 ranks x 8 frames
+    if config == 2:
+        assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"] and line["separate_detect"]["votes_ok"]
+        assert line["planar_i420"]["payload_ok"] and line["dwtdctsvd"]["payload_ok"]
