@@ -235,3 +235,25 @@ def test_fingerprint_bookkeeping():
     votes = {0: (fp.payload_for_segment(0, 1), 1.0), 1: (fp.payload_for_segment(1, 2), 0.9),
              2: (fp.payload_for_segment(7, 0), 0.8)}                                         # segment 2 decodes as 7: reject
     assert fp.identify_copies(votes) == [1, 2, None]
+
+
+def build_abi_demo(out_path):
+    """examples/abi_demo.c with the plain C compiler against the in-tree library and the HIP runtime."""
+    import __graft_entry__ as ge
+    libdir = os.path.dirname(ge.LIB)
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-O2", os.path.join(ROOT, "examples", "abi_demo.c"), "-I", os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L", libdir, "-L/opt/rocm/lib", "-loffmark_hip", "-lamdhip64",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_header_is_plain_c_and_the_c_host_example_links(tmp_path):
+    """include/offmark_hip.h is a C header (no C++, no torch types): a C99 translation unit that only includes it compiles
+    with -pedantic, and the stand-alone C host (examples/abi_demo.c) links against the library and the HIP runtime."""
+    tu = tmp_path / "only_header.c"
+    tu.write_text('#include "offmark_hip.h"\nint main(void) { return ofmk_version() == OFMK_ABI_VERSION ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(tu)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    build_abi_demo(str(tmp_path / "abi_demo"))

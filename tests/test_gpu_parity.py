@@ -1036,3 +1036,17 @@ def test_bench_two_ranks_gloo_on_one_device(config):
     if config == 2:
         assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"] and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["dwtdctsvd"]["payload_ok"]
+
+
+def test_c_host_program_over_the_abi(tmp_path):
+    """examples/abi_demo.c: a plain C process (no Python, no torch in it) allocates with the HIP runtime, marks and verifies
+    with both codecs through the C ABI, reads the written frames with the stand-alone detectors and gets every payload
+    back; an invalid call comes back as an error code with a text."""
+    import subprocess
+    from test_abi_and_host import build_abi_demo
+    exe = str(tmp_path / "abi_demo")
+    build_abi_demo(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.strip().endswith("abi_demo OK") and r.stdout.count("6 of 6 frames carry the payload") == 4
+    assert "refused with code -1" in r.stdout
