@@ -461,6 +461,38 @@ def main():
             dist.destroy_process_group()
         return
 
+    # what the device is doing under this load: one rocm-smi sample (engine clock, socket power) while the steps keep running --
+    # the evidence behind "the socket sits on its power limit" travels with the line
+    if cfg == 2 and a.codec == "dct" and world == 1 and not a.no_extras:
+        try:
+            import re
+            import shutil
+            import subprocess
+            import threading
+            smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+            stop = threading.Event()
+
+            def keep_busy():
+                torch.cuda.set_device(dev)
+                while not stop.is_set():
+                    for _ in range(50):
+                        hot_path(lanes[0]["eng"], lanes[0]["out"])
+                    torch.cuda.synchronize()
+            th = threading.Thread(target=keep_busy, daemon=True)
+            th.start()
+            time.sleep(0.4)
+            try:
+                txt = subprocess.run([smi, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            finally:
+                stop.set()
+                th.join(timeout=30)
+            sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+            power = re.search(r"Power \(W\): ([0-9.]+)", txt)
+            extra["device_under_load"] = dict(sclk_mhz=int(sclk.group(1)) if sclk else None, socket_power_w=float(power.group(1)) if power else None,
+                                              note="one rocm-smi sample while embed+detect steps run back to back")
+        except Exception as exc:
+            extra["device_under_load"] = dict(error=repr(exc))
+
     # PCIe-inclusive rate (never `value`): frames start and end in pinned host memory, three-stream pipeline
     if cfg == 2 and a.codec == "dct" and world == 1 and not a.no_extras and (H, W) == (1080, 1920):
         try:
