@@ -232,3 +232,41 @@ def test_svd_random_shapes_and_contents(eng):
             assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(nblk, 1e-4), (trial, k)
         c3, b3 = eng.svd_detect(cuda(got), 8, want_bits=True)
         assert np.array_equal(c3.cpu().numpy(), counts.cpu().numpy()) and np.array_equal(b3.cpu().numpy(), bits.cpu().numpy())
+
+
+def test_non_finite_and_extreme_tiles_stay_local_and_terminate(eng):
+    """The DwtDctSvd codec has no frame-global step, so a tile of nan / inf / 1e30 / denormals in a float32 YUV frame (the
+    plugin boundary takes any floats) must neither stall the solver's wave-uniform loop (it is capped) nor change any
+    other tile: every clean tile comes out bit-identical to the same frame without the poison, and the read-out of the
+    clean tiles is unchanged.  (What the poisoned tiles themselves become is not specified -- upstream LAPACK raises or
+    returns nan there.)"""
+    import torch
+    rng = np.random.default_rng(31)
+    H, W = 64, 128
+    rgb = rng.integers(0, 256, (H, W, 3)).astype(np.float32)
+    rgb[:, :64] = np.linspace(20, 230, 64, dtype=np.float32)[None, :, None]            # a smooth half and a noisy half
+    clean = orc.bgr2yuv_f32(rgb)
+    wm = orc.shuffle_generate(P8, (1, H * W // 64), 0)
+    poisons = [np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-40, 3e38]
+    bad = clean.copy()
+    where = []
+    for k, v in enumerate(poisons):
+        bi, bj = k % (H // 8), (3 * k + 1) % (W // 8)
+        bad[bi * 8:bi * 8 + 8, bj * 8:bj * 8 + 8, 1] = v
+        if k % 2:
+            bad[bi * 8 + 3, bj * 8 + 5, 1] = 7.0                                       # a mixed tile
+        where.append((bi, bj))
+    for scales in (None, (9.0, 15.0, 20.0)):
+        out_clean = eng.svd_encode_yuv(cuda(clean[None].copy()), wm, scales=scales)
+        out_bad = eng.svd_encode_yuv(cuda(bad[None].copy()), wm, scales=scales)
+        torch.cuda.synchronize()                                                      # returns: the loop terminated
+        a, b = out_clean[0].cpu().numpy(), out_bad[0].cpu().numpy()
+        ok = np.ones((H // 8, W // 8), bool)
+        for bi, bj in where:
+            ok[bi, bj] = False
+        m = np.kron(ok, np.ones((8, 8), bool))
+        assert np.array_equal(a[m], b[m])
+        bits_clean = eng.svd_decode_yuv(out_clean, scales=scales)[0].cpu().numpy()[: ok.size].reshape(ok.shape)
+        bits_bad = eng.svd_decode_yuv(out_bad, scales=scales)[0].cpu().numpy()[: ok.size].reshape(ok.shape)
+        assert np.array_equal(bits_clean[ok], bits_bad[ok])
+        assert np.array_equal(bits_clean[ok], np.asarray(wm).reshape(-1)[: ok.size].reshape(ok.shape)[ok].astype(np.uint8))
