@@ -21,6 +21,10 @@ payloads over the ranks (RCCL; a no-op on one GPU) and take the cross-frame vote
   python bench.py --gpus 1 --steps 100 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...      with N > 1 and no launcher (WORLD_SIZE unset): bench.py starts that same
+                                    torch.distributed.run command itself as a child process, before anything
+                                    touches the GPU, and relays rank 0's line and the exit code.
+`collective.ranks` / `rccl_ranks` = what an all-reduce of ones returned: the ranks the collective library really joined.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (config 2: the fused mark+verify kernel:
 it re-reads each frame, writes the marked frame and analyzes it).  Launch durations (`kernels`) come
@@ -175,8 +179,42 @@ def cpu_baseline(frames_u8, wm, alpha, budget_s):
                 variants=variants)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (one process per GPU over RCCL), relay rank 0's JSON line and the exit code.
+    Nothing in this parent has touched the GPU (no torch import, no HIP call), and the parent is never replaced
+    (no exec): the ranks are ordinary child processes.  Sharding shape: tests/segment_mark_detect_hls.py:407-412
+    (independent segments), here one rank per GPU."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["OFMK_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for text in child.stdout:                                # rank 0 prints the one JSON line; anything else goes to stderr
+        if text.lstrip().startswith("{"):
+            lines.append(text)
+        else:
+            sys.stderr.write(text)
+    rc = child.wait()
+    if lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1                                               # a run without a line is a failed run
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     import torch
     import torch.distributed as dist
     from offmark import _hip
@@ -198,6 +236,11 @@ def main():
     dev = torch.device("cuda", local)
     lib = _hip.load()
     flags = _hip.F_SEPARATE_DETECT if a.separate_detect else 0
+    ranks_seen = 1
+    if grouped:                                   # how many ranks the collective library really connected: sum of ones
+        one = torch.ones(1, dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     # ---- workload ------------------------------------------------------------------------------------
     cfg = a.config
@@ -616,6 +659,9 @@ def main():
                  "frac_of_measured_copy": round(path_gbps / (copy_gbps * world), 4)},
         "hbm_copy_GBps": round(copy_gbps, 1), "hbm_read_GBps": round(read_gbps, 1),
         "source_sha16": sha,
+        "collective": {"backend": ("rccl" if a.backend == "nccl" else a.backend) if grouped else None, "ranks": ranks_seen,
+                       "self_launched": bool(os.environ.get("OFMK_BENCH_SELF_LAUNCHED"))},
+        "rccl_ranks": ranks_seen if (grouped and a.backend == "nccl") else None,
         "host_ms_per_step": host_ms,            # rank 0's CPU time issuing a step / voting on one; must stay < ms_per_step
         "cpu_baseline": base,
     }

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -113,3 +114,21 @@ def _worker8(rank, world, port, n_total, q):
         q.put((rank, {int(k): (v[0].tolist(), v[1]) for k, v in votes.items()}))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.skipif("__import__('torch').cuda.is_available()")
+def test_bench_starts_its_own_ranks_and_relays_their_failure():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (a child torch.distributed.run;
+    the parent never touches the GPU).  Without a GPU the ranks must fail loudly (no CPU fallback), and the parent must
+    hand that on: non-zero exit code, no JSON line.  The working two-rank run is the -m gpu test
+    test_bench_two_ranks_gloo_on_one_device[...-self]."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                        "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr          # two ranks were really started

@@ -1011,28 +1011,35 @@ def test_bench_configs_run_at_one_gpu(config, extra):
         assert line["pcie_inclusive"]["i420"]["frames_per_s"] > 0 and line["pcie_inclusive"]["rgb24"]["frames_per_s"] > 0
 
 
-@pytest.mark.parametrize("config", [4, 2])
-def test_bench_two_ranks_gloo_on_one_device(config):
+@pytest.mark.parametrize("config,launcher", [(4, "driver"), (2, "self"), (4, "self")])
+def test_bench_two_ranks_gloo_on_one_device(config, launcher):
     """The N>1 flow of bench.py (sharding of segments / frames over ranks, all-gather of the payloads, vote on every
     rank, MAX over ranks) with two processes on the one GPU of the box, gloo standing in for RCCL (a one-GPU box cannot
-    run RCCL across ranks)."""
+    run RCCL across ranks).  launcher "driver": started the way the driver starts it (torch.distributed.run around
+    bench.py); "self": plain `python bench.py --gpus 2 ...`, bench.py spawns its own ranks."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     import socket
-    with socket.socket() as sock:                  # a port that is free now (the two parametrised runs follow each other)
+    with socket.socket() as sock:                  # a port that is free now (the parametrised runs follow each other)
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
-           "--config", str(config), "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline"] + (["--no-extras"] if config != 2 else [])      # config 2: the side measurements run on every rank too
+    head = [sys.executable]
+    if launcher == "driver":
+        head += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", str(port)]
+    cmd = head + [os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                  "--config", str(config), "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
+                  "--no-cpu-baseline"] + (["--no-extras"] if config != 2 else [])      # config 2: the side measurements run on every rank too
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    out_lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(out_lines) == 1, r.stdout[-2000:]
+    line = json.loads(out_lines[-1])
     assert line["n_gpus"] == 2 and line["payload_bit_exact"]
+    assert line["collective"] == {"backend": "gloo", "ranks": 2, "self_launched": launcher == "self"} and line["rccl_ranks"] is None
     assert line["config"]["frames_per_gpu"] == (8 if config == 2 else 4 * 8)      # config 4: 8 segments / 2 ranks x 8 frames
     if config == 2:
         assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"] and line["separate_detect"]["votes_ok"]
