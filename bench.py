@@ -549,6 +549,18 @@ def main():
                                                     "H2D / kernels / D2H on three streams); tools/pcie_pipeline.py")
         except Exception as exc:
             extra["pcie_inclusive"] = dict(error=repr(exc))
+        # the same crossing through the PRODUCT's plugin loop: offmark.video.embedder.Embedder / extractor.Extractor over
+        # host frames (what tests/mark.py / tests/detect.py drive), tools/plugin_pipeline_rate.py
+        try:
+            import plugin_pipeline_rate
+            pp = plugin_pipeline_rate.measure(n=800, B=50, H=H, W=W, forms=("rgb24", "yuv420p"))
+            pp.update(plugin_pipeline_rate.measure(n=300, B=50, H=H, W=W, forms=("pageable",)))
+            extra["plugin_pipeline"] = dict(pp, note="Embedder.start() / Extractor.start() over frames in host memory, three-stream "
+                                                     "pipeline inside the plugin classes (offmark/video/pipeline.py): *_pinned = page-locked "
+                                                     "reader and writer memory (no host copy), pageable = plain ndarrays in and out (two "
+                                                     "threaded host copies per frame)")
+        except Exception as exc:
+            extra["plugin_pipeline"] = dict(error=repr(exc))
 
     # achievable HBM bandwidth of this device, same run: 16-byte streaming copy (read + write) and read-only stream
     if frames.numel() >= (1 << 28) and out is not None:

@@ -1,0 +1,214 @@
+"""The plugin-level frame loop (offmark.video.embedder.Embedder / extractor.Extractor; reference
+src/offmark/video/embedder.py:18-31, extractor.py:18-28) as a three-stream pipeline (offmark/video/pipeline.py).
+
+A pipeline must not change a single byte: every form of hand-over (page-locked reader, page-locked writer block,
+staging copies, per-frame read()/write() of duck-typed objects, rgb24 and 4:2:0 planes, mixed formats) is compared
+BIT FOR BIT with one direct batch call of the engine on the same frames -- which the parity tests
+(tests/test_gpu_parity.py, tests/test_gpu_planar.py) compare with the oracle.  Order of frames, ragged last batch,
+more batches than pipeline slots, empty streams and a reader that fails mid-stream are covered.
+"""
+import numpy as np
+import pytest
+
+import offmark_oracle as orc
+
+pytestmark = pytest.mark.gpu
+P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+H, W = 64, 96
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    from offmark.engine import DctEngine
+    torch.cuda.set_device(0)
+    return DctEngine()
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def frames_rgb(n, h=H, w=W, seed=500):
+    return np.stack([orc.synthetic_frame(h, w, seed + i) for i in range(n)])
+
+
+def make_codec(codec, h=H, w=W):
+    from offmark.generator.shuffler import Shuffler
+    if codec == "dct":
+        from offmark.embed.dct_encoder import DctEncoder as Enc
+        from offmark.extract.dct_decoder import DctDecoder as Dec
+    else:
+        from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder as Enc
+        from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder as Dec
+    enc = Enc()
+    enc.read_wm(Shuffler(key=0).generate_wm(P8, enc.wm_capacity((h, w, 3))))
+    return enc, Dec()
+
+
+class BareReader:
+    """Only what the reference's FrameReader promises: read() and close() -- no size, no batches."""
+
+    def __init__(self, frames, fail_at=None):
+        self.frames, self.pos, self.fail_at, self.closed = frames, 0, fail_at, False
+
+    def read(self):
+        if self.fail_at is not None and self.pos == self.fail_at:
+            raise IOError("decoder died")
+        if self.pos >= len(self.frames):
+            return None
+        self.pos += 1
+        return self.frames[self.pos - 1]
+
+    def close(self):
+        self.closed = True
+
+
+class BareWriter:
+    def __init__(self):
+        self.frames, self.closed = [], False
+
+    def write(self, frame):
+        self.frames.append(np.array(frame))           # the pipeline hands out views of its staging buffer
+
+    def close(self):
+        self.closed = True
+
+
+@pytest.mark.parametrize("codec", ["dct", "dwtdctsvd"])
+@pytest.mark.parametrize("form", ["pinned", "registered", "pageable", "bare"])
+def test_embedder_pipeline_equals_one_direct_batch_call(eng, codec, form):
+    from offmark.video.embedder import Embedder
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark.video.frame_writer import ArrayFrameWriter
+    from offmark.video.pipeline import pinned_empty
+    n, B = 23, 5                                     # 5 batches (more than the 2 slots), ragged last one
+    src = frames_rgb(n)
+    enc, _ = make_codec(codec)
+    want = enc.encode_frames_u8(cuda(src)).cpu().numpy()
+    if form == "pinned":
+        host = pinned_empty(src.shape)
+        host[:] = src
+        r, w = ArrayFrameReader(host, pin="already"), ArrayFrameWriter(capacity=n, frame_shape=src.shape[1:])
+    elif form == "registered":
+        r, w = ArrayFrameReader(src.copy(), pin=True), ArrayFrameWriter(capacity=n - 7, frame_shape=src.shape[1:])   # block too small: falls back
+    elif form == "pageable":
+        r, w = ArrayFrameReader(src), ArrayFrameWriter()
+    else:
+        r, w = BareReader(list(src)), BareWriter()
+    emb = Embedder(r, enc, w, batch_frames=B)
+    emb.start()
+    assert emb.frames_marked == n and len(w.frames) == n and r.closed and w.closed
+    assert np.array_equal(np.stack(w.frames), want)
+    if form == "pinned":
+        assert np.array_equal(w.array(), want)
+
+
+@pytest.mark.parametrize("layout,fmt", [("i420", "yuv420p"), ("nv12", "nv12")])
+def test_planar_readers_and_writers(eng, layout, fmt):
+    """yuv420p / nv12 frames [H*3/2, W] through Embedder and Extractor == the engine's planar batch calls; mixed
+    reader / writer formats == the explicit conversion chain."""
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.video.embedder import Embedder
+    from offmark.video.extractor import Extractor
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark.video.frame_writer import ArrayFrameWriter
+    n, B, h, w = 11, 4, 240, 320
+    rgb = frames_rgb(n, h, w, seed=1001)
+    enc, dec = make_codec("dct", h, w)
+    planes = eng.rgb_to_yuv420(cuda(rgb), layout)
+    want = eng.embed_yuv420(planes, h, w, enc._device_wm(h * w // 64), layout=layout).cpu().numpy()
+    src = planes.cpu().numpy().reshape(n, h * 3 // 2, w)
+    wr = ArrayFrameWriter(pix_fmt=fmt)
+    Embedder(ArrayFrameReader(src, pix_fmt=fmt), enc, wr, batch_frames=B).start()
+    got = np.stack(wr.frames)
+    assert got.shape == src.shape and np.array_equal(got.reshape(n, -1), want)
+    ex = Extractor(ArrayFrameReader(got, pix_fmt=fmt), dec, DeShuffler(key=0).set_shape(P8.shape), batch_frames=B)
+    ex.start()
+    assert len(ex.patterns) == n and all(np.array_equal(p, P8) for p in ex.patterns)      # survives its own 4:2:0 subsampling
+    # rgb24 in, planes out: mark in RGB, convert on the device
+    wr2 = ArrayFrameWriter(pix_fmt=fmt)
+    Embedder(ArrayFrameReader(rgb), enc, wr2, batch_frames=B).start()
+    chain = eng.rgb_to_yuv420(enc.encode_frames_u8(cuda(rgb)), layout).cpu().numpy()
+    assert np.array_equal(np.stack(wr2.frames).reshape(n, -1), chain)
+    # planes in, rgb24 out
+    wr3 = ArrayFrameWriter()
+    Embedder(ArrayFrameReader(src, pix_fmt=fmt), enc, wr3, batch_frames=B).start()
+    chain3 = enc.encode_frames_u8(eng.yuv420_to_rgb(planes, h, w, layout)).cpu().numpy()
+    assert np.array_equal(np.stack(wr3.frames), chain3)
+    # a codec without planar kernels (DwtDctSvd) takes the conversion route on the device
+    enc_s, dec_s = make_codec("dwtdctsvd", h, w)
+    wr4 = ArrayFrameWriter(pix_fmt=fmt)
+    Embedder(ArrayFrameReader(src, pix_fmt=fmt), enc_s, wr4, batch_frames=B).start()
+    chain4 = eng.rgb_to_yuv420(enc_s.encode_frames_u8(eng.yuv420_to_rgb(planes, h, w, layout)), layout).cpu().numpy()
+    assert np.array_equal(np.stack(wr4.frames).reshape(n, -1), chain4)
+    ex4 = Extractor(ArrayFrameReader(np.stack(wr4.frames), pix_fmt=fmt), dec_s, DeShuffler(key=0).set_shape(P8.shape), batch_frames=B)
+    ex4.start()
+    want_counts, _ = dec_s.decode_frames_u8(eng.yuv420_to_rgb(cuda(chain4), h, w, layout), 8)
+    want_payloads = DeShuffler(key=0).set_shape(P8.shape).degenerate_counts(want_counts.cpu().numpy(), h * w // 64)
+    assert np.array_equal(np.stack(ex4.patterns), want_payloads)
+
+
+@pytest.mark.parametrize("codec", ["dct", "dwtdctsvd"])
+def test_extractor_pipeline_equals_direct_detect(eng, codec):
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.video.extractor import Extractor
+    from offmark.video.frame_reader import ArrayFrameReader
+    n, B = 19, 4
+    enc, dec = make_codec(codec)
+    marked = enc.encode_frames_u8(cuda(frames_rgb(n))).cpu().numpy()
+    counts, _ = dec.decode_frames_u8(cuda(marked), 8)
+    want = DeShuffler(key=0).set_shape(P8.shape).degenerate_counts(counts.cpu().numpy(), H * W // 64)
+    for reader in (ArrayFrameReader(marked), ArrayFrameReader(marked.copy(), pin=True), BareReader(list(marked))):
+        ex = Extractor(reader, dec, DeShuffler(key=0).set_shape(P8.shape), batch_frames=B)
+        ex.start()
+        assert reader.closed and np.array_equal(np.stack(ex.patterns), want)
+        assert np.array_equal(ex.most_common()[0], P8)
+
+
+def test_empty_stream_and_failing_reader(eng):
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.video.embedder import Embedder
+    from offmark.video.extractor import Extractor
+    enc, dec = make_codec("dct")
+    r, w = BareReader([]), BareWriter()
+    emb = Embedder(r, enc, w, batch_frames=4)
+    emb.start()
+    assert emb.frames_marked == 0 and w.frames == [] and r.closed and w.closed
+    ex = Extractor(BareReader([]), dec, DeShuffler(key=0).set_shape(P8.shape))
+    ex.start()
+    assert ex.patterns == [] and ex.most_common() == (None, None)
+    # the reader dies at frame 9 of 14: the error reaches the caller (no hang, no silent truncation); what was
+    # complete before it is written, in order
+    src = frames_rgb(14)
+    w2 = BareWriter()
+    emb2 = Embedder(BareReader(list(src), fail_at=9), enc, w2, batch_frames=4)
+    with pytest.raises(IOError, match="decoder died"):
+        emb2.start()
+    want = enc.encode_frames_u8(cuda(src[:8])).cpu().numpy()
+    assert emb2.frames_marked == len(w2.frames) == 8
+    assert np.array_equal(np.stack(w2.frames), want)
+    # a frame of the wrong size in the middle of the stream is refused, not read out of bounds
+    bad = list(src[:6]) + [np.zeros((H + 8, W, 3), np.uint8)]
+    with pytest.raises(ValueError, match="expected"):
+        Embedder(BareReader(bad), enc, BareWriter(), batch_frames=4).start()
+
+
+def test_engine_refuses_a_bad_destination(eng):
+    """`out` goes to the kernels as a raw pointer, so it is checked first."""
+    import torch
+    f = cuda(frames_rgb(2))
+    wm = np.zeros((1, H * W // 64), np.uint8)
+    for bad in (torch.empty_like(f).cpu(), torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda"),
+                torch.empty((2, H, W, 3), dtype=torch.float32, device="cuda"),
+                torch.empty((2, H, W, 6), dtype=torch.uint8, device="cuda")[..., ::2]):
+        for call in (lambda o: eng.embed(f, wm, out=o), lambda o: eng.svd_embed(f, wm, out=o),
+                     lambda o: eng.embed_detect(f, wm, 8, out=o)):
+            with pytest.raises(ValueError, match="out must be"):
+                call(bad)
+    planes = eng.rgb_to_yuv420(f)
+    with pytest.raises(ValueError, match="out must be"):
+        eng.embed_yuv420(planes, H, W, wm, out=torch.empty_like(planes).cpu())
+    with pytest.raises(ValueError, match="unknown 4:2:0 layout"):
+        eng.embed_yuv420(planes, H, W, wm, layout="yv12")

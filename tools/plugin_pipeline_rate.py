@@ -1,26 +1,86 @@
-"""Frames/s of the plugin-level pipeline (Embedder / Extractor over in-memory 1080p frames on the HOST)."""
-import os, sys, time
+"""Frames/s of the plugin-level pipeline: offmark.video.embedder.Embedder / extractor.Extractor over 1080p frames that
+start and end in HOST memory, i.e. what tests/mark.py / tests/detect.py drive (reference src/offmark/video/embedder.py:18-31).
+Compare with bench.py's `pcie_inclusive` (tools/pcie_pipeline.py: the same three-stream pipeline written out by hand).
+
+forms:
+  rgb24 / yuv420p "pinned"    reader over page-locked frames (ArrayFrameReader(pin="already")), writer that hands out
+                              page-locked memory (ArrayFrameWriter(capacity=...)): no host copy at either end
+  rgb24 "pageable"            plain ndarray in, ArrayFrameWriter that copies every batch: two host copies per frame
+                              (threaded), what a caller gets who changes nothing
+usage: python tools/plugin_pipeline_rate.py [frames] [batch]"""
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "video-fingerprinting_amd"))
-import numpy as np, torch
-from offmark.degenerator.de_shuffler import DeShuffler
-from offmark.embed.dct_encoder import DctEncoder
-from offmark.extract.dct_decoder import DctDecoder
-from offmark.generator.shuffler import Shuffler
-from offmark.synthetic import synthetic_frames
-from offmark.video.embedder import Embedder
-from offmark.video.extractor import Extractor
-from offmark.video.frame_reader import ArrayFrameReader
-from offmark.video.frame_writer import ArrayFrameWriter
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-frames = synthetic_frames(50, 1080, 1920, seed=3).cpu().numpy()
-frames = np.concatenate([frames] * (n // 50))
+
+import numpy as np  # noqa: E402
+
 P = np.array([0, 1, 1, 0, 0, 1, 0, 1])
-for rep in range(2):
-    enc = DctEncoder(); enc.read_wm(Shuffler(key=0).generate_wm(P, enc.wm_capacity((1080, 1920, 3))))
-    w = ArrayFrameWriter()
-    t0 = time.perf_counter(); Embedder(ArrayFrameReader(frames), enc, w).start(); t1 = time.perf_counter()
-    ex = Extractor(ArrayFrameReader(w.frames), DctDecoder(), DeShuffler(key=0).set_shape(P.shape))
-    t2 = time.perf_counter(); ex.start(); t3 = time.perf_counter()
-    ok = all(np.array_equal(p, P) for p in ex.patterns)
-    print(f"rep {rep}: Embedder {len(frames) / (t1 - t0):.0f} frames/s, Extractor {len(frames) / (t3 - t2):.0f} frames/s, payloads ok: {ok}")
+
+
+def measure(n=400, B=50, H=1080, W=1920, reps=2, forms=("rgb24", "yuv420p", "pageable"), codec="dct"):
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.generator.shuffler import Shuffler
+    from offmark.synthetic import synthetic_frames
+    from offmark.video.embedder import Embedder
+    from offmark.video.extractor import Extractor
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark.video.frame_writer import ArrayFrameWriter
+    from offmark.video.pipeline import frame_shape, pinned_empty
+    if codec == "dct":
+        from offmark.embed.dct_encoder import DctEncoder as Enc
+        from offmark.extract.dct_decoder import DctDecoder as Dec
+    else:
+        from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder as Enc
+        from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder as Dec
+    enc = Enc()
+    enc.read_wm(Shuffler(key=0).generate_wm(P, enc.wm_capacity((H, W, 3))))
+    dec = Dec()
+    base = synthetic_frames(B, H, W, seed=3)
+    out = {}
+    for form in forms:
+        fmt = "rgb24" if form == "pageable" else form
+        shape = frame_shape(fmt, H, W)
+        src_dev = base if fmt == "rgb24" else enc.engine.rgb_to_yuv420(base).view((B,) + shape)
+        src = src_dev.cpu().numpy()
+        if form == "pageable":
+            host_in = np.concatenate([src] * (n // B))
+        else:
+            host_in = pinned_empty((n,) + shape)
+            for i in range(0, n, B):
+                host_in[i:i + B] = src[: min(B, n - i)]
+        best = {}
+        for _ in range(reps):
+            r = ArrayFrameReader(host_in, pix_fmt=fmt, pin=False if form == "pageable" else "already")
+            w = ArrayFrameWriter(pix_fmt=fmt) if form == "pageable" else ArrayFrameWriter(pix_fmt=fmt, capacity=n, frame_shape=shape)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            Embedder(r, enc, w, batch_frames=B).start()
+            t1 = time.perf_counter()
+            marked = np.stack(w.frames) if form == "pageable" else w.array()
+            ex = Extractor(ArrayFrameReader(marked, pix_fmt=fmt, pin=False if form == "pageable" else "already"), dec,
+                           DeShuffler(key=0).set_shape(P.shape), batch_frames=B)
+            t2 = time.perf_counter()
+            ex.start()
+            t3 = time.perf_counter()
+            ok = len(ex.patterns) == n and all(np.array_equal(p, P) for p in ex.patterns)
+            best = dict(embedder_fps=round(max(best.get("embedder_fps", 0), n / (t1 - t0)), 1),
+                        extractor_fps=round(max(best.get("extractor_fps", 0), n / (t3 - t2)), 1),
+                        payloads_ok=bool(ok and best.get("payloads_ok", True)))
+            del w, ex, marked
+        best["GBps_each_way_embedder"] = round(best["embedder_fps"] * int(np.prod(shape)) / 1e9, 2)
+        out[form if form == "pageable" else f"{form}_pinned"] = best
+        del host_in
+    return out
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    for codec in ("dct", "dwtdctsvd"):
+        for form, v in measure(n, B, codec=codec).items():
+            print(f"{codec:9s} {form:15s}: Embedder {v['embedder_fps']:8.0f} frames/s ({v['GBps_each_way_embedder']} GB/s each way), "
+                  f"Extractor {v['extractor_fps']:8.0f} frames/s, payloads ok: {v['payloads_ok']}")

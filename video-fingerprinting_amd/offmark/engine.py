@@ -62,6 +62,24 @@ class DctEngine:
         n, H, W, _ = frames.shape
         return n, H, W
 
+    def _out(self, out, like, shape=None):
+        """The destination of a call: a fresh tensor, or the caller's, which must be a contiguous CUDA tensor of the
+        expected shape (default: ``like``'s), ``like``'s dtype and device -- the kernels write through its raw pointer."""
+        t = self.torch
+        shape = tuple(like.shape if shape is None else shape)
+        if out is None:
+            return t.empty(shape, dtype=like.dtype, device=like.device)
+        if not (isinstance(out, t.Tensor) and out.is_cuda and out.device == like.device and out.dtype == like.dtype
+                and tuple(out.shape) == shape and out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous CUDA {like.dtype} tensor of shape {shape} on {like.device}")
+        return out
+
+    def _layout(self, layout):
+        try:
+            return self._LAYOUT[layout]
+        except KeyError:
+            raise ValueError(f"unknown 4:2:0 layout {layout!r}: one of {sorted(self._LAYOUT)}") from None
+
     def _wm(self, wm, N):
         t = self.torch
         if isinstance(wm, np.ndarray):
@@ -98,8 +116,7 @@ class DctEngine:
         N = H * W // 64
         wm = self._wm(wm, N)
         rows = self._rows(wm_row, n, wm.shape[0])
-        if out is None:
-            out = t.empty_like(frames)
+        out = self._out(out, frames)
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
@@ -139,8 +156,7 @@ class DctEngine:
         N = H * W // 64
         wm = self._wm(wm, N)
         rows = self._rows(wm_row, n, wm.shape[0])
-        if out is None:
-            out = t.empty_like(frames)
+        out = self._out(out, frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
         cf = self._chunk(n, H, W)
@@ -182,11 +198,10 @@ class DctEngine:
         n = self._check_planar(planes, H, W)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
-        if out is None:
-            out = t.empty_like(planes)
+        out = self._out(out, planes)
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
-        _hip.check(self.lib.ofmk_embed_yuv420(planes.data_ptr(), out.data_ptr(), self._LAYOUT[layout], n, H, W, wm.data_ptr(),
+        _hip.check(self.lib.ofmk_embed_yuv420(planes.data_ptr(), out.data_ptr(), self._layout(layout), n, H, W, wm.data_ptr(),
                                               wm.shape[0], _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
                                               _hip.current_stream(), _hip.opts_ref(self.opts)))
         return out
@@ -198,7 +213,7 @@ class DctEngine:
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
-        _hip.check(self.lib.ofmk_detect_yuv420(planes.data_ptr(), self._LAYOUT[layout], n, H, W, int(L), float(alpha),
+        _hip.check(self.lib.ofmk_detect_yuv420(planes.data_ptr(), self._layout(layout), n, H, W, int(L), float(alpha),
                                                counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
                                                _hip.current_stream(), _hip.opts_ref(self.opts)))
         return counts, bits
@@ -209,33 +224,32 @@ class DctEngine:
         n = self._check_planar(planes, H, W)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
-        if out is None:
-            out = t.empty_like(planes)
+        out = self._out(out, planes)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
-        _hip.check(self.lib.ofmk_embed_detect_yuv420(planes.data_ptr(), out.data_ptr(), self._LAYOUT[layout], n, H, W,
+        _hip.check(self.lib.ofmk_embed_detect_yuv420(planes.data_ptr(), out.data_ptr(), self._layout(layout), n, H, W,
                                                      wm.data_ptr(), wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
                                                      counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
                                                      _hip.current_stream(), _hip.opts_ref(self.opts)))
         return out, counts, bits
 
-    def yuv420_to_rgb(self, planes, H, W, layout="i420"):
+    def yuv420_to_rgb(self, planes, H, W, layout="i420", out=None):
         t = self.torch
         n = self._check_planar(planes, H, W)
-        rgb = t.empty((n, H, W, 3), dtype=t.uint8, device=self.device)
-        _hip.check(self.lib.ofmk_yuv420_to_rgb8(planes.data_ptr(), rgb.data_ptr(), self._LAYOUT[layout], n, H, W,
+        rgb = self._out(out, planes, (n, H, W, 3))
+        _hip.check(self.lib.ofmk_yuv420_to_rgb8(planes.data_ptr(), rgb.data_ptr(), self._layout(layout), n, H, W,
                                                 _hip.current_stream()))
         return rgb
 
-    def rgb_to_yuv420(self, frames, layout="i420"):
+    def rgb_to_yuv420(self, frames, layout="i420", out=None):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         if H % 8 or W % 8:
             raise ValueError("planar 4:2:0 frames need H and W to be multiples of 8")
-        planes = t.empty((n, H * W * 3 // 2), dtype=t.uint8, device=self.device)
-        _hip.check(self.lib.ofmk_rgb8_to_yuv420(frames.data_ptr(), planes.data_ptr(), self._LAYOUT[layout], n, H, W,
+        planes = self._out(out, frames, (n, H * W * 3 // 2))
+        _hip.check(self.lib.ofmk_rgb8_to_yuv420(frames.data_ptr(), planes.data_ptr(), self._layout(layout), n, H, W,
                                                 _hip.current_stream()))
         return planes
 
@@ -269,8 +283,7 @@ class DctEngine:
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
-        if out is None:
-            out = t.empty_like(frames)
+        out = self._out(out, frames)
         _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
                                                 _hip.ptr(rows), _hip.scales3(scale, scales), _hip.current_stream(),
                                                 _hip.opts_ref(self.opts)))
@@ -290,8 +303,7 @@ class DctEngine:
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
-        if out is None:
-            out = t.empty_like(frames)
+        out = self._out(out, frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),

@@ -3,9 +3,10 @@
 frame_writer).start()`` reads until ``read()`` returns None, marks, writes, closes both ends.
 
 Two paths:
-  * batched GPU path, when ``frame_embedder`` offers ``encode_frames_u8`` (the HIP DctEncoder):
-    up to ``batch_frames`` frames per launch go to the device as u8 RGB, the whole reference
-    frame step (embedder.py:33-39) runs in the kernels, marked u8 frames come back;
+  * batched GPU path, when ``frame_embedder`` offers ``encode_frames_u8`` (the HIP codecs):
+    up to ``batch_frames`` frames per launch go to the device as u8 (RGB, or 4:2:0 planes when the
+    reader says so), the whole reference frame step (embedder.py:33-39) runs in the kernels, marked u8
+    frames come back -- pipelined over three streams, see offmark.video.pipeline;
   * generic path for any other duck-typed encoder: the reference's per-frame sequence
     u8 -> f32 -> BGR2YUV -> encode(yuv) -> YUV2BGR -> clip -> around -> u8 on the host.
 """
@@ -47,49 +48,42 @@ class Embedder:
             self.frames_marked += 1
 
     def __run_batched(self):
-        """Two batches in flight: while batch k runs on the GPU and drains into a pinned host buffer, batch
-        k-1 is handed to the writer.  (Frames cross PCIe twice here; bench.py measures HBM-resident frames.)"""
-        import torch
-        dev = self.frame_embedder.engine.device
-        read_batch = getattr(self.frame_reader, "read_batch", None)
-        pinned, done, pending = [None, None], [torch.cuda.Event(), torch.cuda.Event()], None
-        k = 0
-        while True:
-            batch = read_batch(self.batch_frames) if read_batch else self.__collect()
-            if batch is not None:
-                slot = k & 1
-                src = torch.from_numpy(np.ascontiguousarray(batch))
-                if pinned[slot] is None or pinned[slot].shape[1:] != src.shape[1:] or pinned[slot].shape[0] < src.shape[0]:
-                    pinned[slot] = torch.empty((self.batch_frames,) + tuple(src.shape[1:]), dtype=torch.uint8).pin_memory()
-                marked = self.frame_embedder.encode_frames_u8(src.to(dev, non_blocking=True))
-                pinned[slot][: len(src)].copy_(marked, non_blocking=True)
-                done[slot].record()
-            if pending is not None:
-                slot, count = pending
-                done[slot].synchronize()
-                self.__write_all(pinned[slot][:count].numpy())
-                self.frames_marked += count
-            if batch is None:
+        """The frame loop as a three-stream pipeline (offmark.video.pipeline): upload, kernels and download of
+        neighbouring batches overlap, the reader is read ahead on a helper thread, and page-locked memory is used at
+        both ends -- the reader's / writer's own when they offer it, staging buffers otherwise.  Readers and
+        writers may carry ``pix_fmt`` "yuv420p" / "nv12": the planes cross PCIe (half the bytes) and the conversion
+        is fused into the kernels (or done on the device when the codec has no planar kernels)."""
+        from . import pipeline as pl
+        enc = self.frame_embedder
+        eng = enc.engine
+        reader = self.frame_reader
+        if not (hasattr(reader, "height") and hasattr(reader, "width")):
+            reader = pl.PeekedReader(reader)
+            if reader.first is None:
                 logger.info("End of input stream")
-                break
-            pending = (k & 1, len(batch))
-            k += 1
+                return
+        H, W = int(reader.height), int(reader.width)
+        in_fmt, out_fmt = pl.pix_fmt_of(reader), pl.pix_fmt_of(self.frame_writer)
+        fused_planar = in_fmt == out_fmt != "rgb24" and hasattr(enc, "encode_planes_yuv420")
 
-    def __write_all(self, frames):
-        if hasattr(self.frame_writer, "write_batch"):
-            self.frame_writer.write_batch(frames)
-        else:
-            for f in frames:
-                self.frame_writer.write(f)
+        def process(dev_in, dev_out):
+            m = dev_in.shape[0]
+            if fused_planar:
+                enc.encode_planes_yuv420(dev_in.view(m, -1), H, W, out=dev_out.view(m, -1), layout=pl.PLANAR_LAYOUT[in_fmt])
+                return
+            rgb = pl.to_rgb_on_device(eng, dev_in, in_fmt, H, W)
+            if out_fmt == "rgb24":
+                enc.encode_frames_u8(rgb, out=dev_out)
+            else:
+                eng.rgb_to_yuv420(enc.encode_frames_u8(rgb), layout=pl.PLANAR_LAYOUT[out_fmt], out=dev_out.view(m, -1))
 
-    def __collect(self):
-        frames = []
-        while len(frames) < self.batch_frames:
-            f = self.frame_reader.read()
-            if f is None:
-                break
-            frames.append(f)
-        return np.stack(frames) if frames else None
+        pipe = pl.StagedPipeline(eng.device, reader, self.batch_frames, pl.frame_shape(in_fmt, H, W),
+                                 pl.frame_shape(out_fmt, H, W), np.uint8)
+        try:
+            pipe.run(process, pl.WriterSink(self.frame_writer))
+        finally:
+            self.frames_marked += pipe.frames_done
+        logger.info("End of input stream")
 
     def __mark_frame(self, frame_rgb):
         frame_yuv = bgr2yuv(frame_rgb.astype(np.float32))

@@ -49,31 +49,40 @@ class Extractor:
         return vote(np.stack(flat)) if flat else (None, None)
 
     def __run_batched(self):
-        import torch
+        """The same three-stream pipeline as the Embedder's (offmark.video.pipeline), two batches in flight: while
+        batch k's frames upload and its kernels run, batch k-1's counts come back and are degenerated on the host.
+        Only [n, L] int32 counts travel device -> host."""
+        from . import pipeline as pl
+        dec = self.frame_extractor
+        eng = dec.engine
         L = self.degenerator.payload_len
-        while True:
-            batch = self.__next_batch()
-            if batch is None:
+        reader = self.frame_reader
+        if not (hasattr(reader, "height") and hasattr(reader, "width")):
+            reader = pl.PeekedReader(reader)
+            if reader.first is None:
                 logger.info("End of input stream")
-                break
-            n, h, w, _ = batch.shape
-            dev = torch.from_numpy(np.ascontiguousarray(batch)).to(self.frame_extractor.engine.device)
-            counts, _ = self.frame_extractor.decode_frames_u8(dev, L)
-            outs = self.degenerator.degenerate_counts(counts.cpu().numpy(), h * w // 64)
-            for out in outs:
-                self.patterns.append(out)
-                logger.info(out)
+                return
+        H, W = int(reader.height), int(reader.width)
+        fmt = pl.pix_fmt_of(reader)
+        planar = fmt != "rgb24" and hasattr(dec, "decode_planes_yuv420")
 
-    def __next_batch(self):
-        if hasattr(self.frame_reader, "read_batch"):
-            return self.frame_reader.read_batch(self.batch_frames)
-        frames = []                                   # duck-typed reader with only read()/close()
-        while len(frames) < self.batch_frames:
-            f = self.frame_reader.read()
-            if f is None:
-                break
-            frames.append(f)
-        return np.stack(frames) if frames else None
+        def process(dev_in, dev_out):
+            if planar:
+                counts, _ = dec.decode_planes_yuv420(dev_in.view(dev_in.shape[0], -1), H, W, L, layout=pl.PLANAR_LAYOUT[fmt])
+            else:
+                counts, _ = dec.decode_frames_u8(pl.to_rgb_on_device(eng, dev_in, fmt, H, W), L)
+            dev_out.copy_(counts)
+
+        outer = self
+
+        class Sink:
+            def deliver(self, counts):
+                for out in outer.degenerator.degenerate_counts(counts, H * W // 64):
+                    outer.patterns.append(out)
+                    logger.info(out)
+
+        pl.StagedPipeline(eng.device, reader, self.batch_frames, pl.frame_shape(fmt, H, W), (L,), np.int32).run(process, Sink())
+        logger.info("End of input stream")
 
     def __check_frame(self, frame_rgb):
         wm_frame_yuv = bgr2yuv(frame_rgb.astype(np.float32))
