@@ -93,12 +93,12 @@ int main(void) {
     int ok = 1;
     /* DCT codec: mark + verify in one call, then the stand-alone detector on the written frames */
     CHECK_OFMK(ofmk_embed_detect_rgb8(d_in, d_out, N_FRAMES, H, W, d_wm, 1, NULL, 20.0, L, d_counts, NULL, 0, d_ws, ws_bytes, stream, NULL));
-    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream));
+    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream, NULL));
     CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     ok &= payloads_ok(h_payload, "DCT       ofmk_embed_detect_rgb8");
     CHECK_OFMK(ofmk_detect_rgb8(d_out, N_FRAMES, H, W, L, 20.0, d_counts, NULL, 0, d_ws, ws_bytes, stream, NULL));
-    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream));
+    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream, NULL));
     CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     ok &= payloads_ok(h_payload, "DCT       ofmk_detect_rgb8 on the output");
@@ -106,12 +106,12 @@ int main(void) {
     /* DwtDctSvd codec (what tests/mark.py constructs), scales = [0, 15, 0] */
     const double scales[3] = {0.0, 15.0, 0.0};
     CHECK_OFMK(ofmk_svd_embed_detect_rgb8(d_in, d_out, N_FRAMES, H, W, d_wm, 1, NULL, scales, L, d_counts, NULL, stream, NULL));
-    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream));
+    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream, NULL));
     CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     ok &= payloads_ok(h_payload, "DwtDctSvd ofmk_svd_embed_detect_rgb8");
     CHECK_OFMK(ofmk_svd_detect_rgb8(d_out, N_FRAMES, H, W, L, scales, d_counts, NULL, stream, NULL));
-    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream));
+    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream, NULL));
     CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     ok &= payloads_ok(h_payload, "DwtDctSvd ofmk_svd_detect_rgb8 on the output");

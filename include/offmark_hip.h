@@ -13,7 +13,8 @@
  *     compute call may be captured into a hipGraph (unless it carries an ofmk_timing object);
  *   - re-entrant: the library has NO mutable state besides the calling thread's error text.
  *     Everything a call needs arrives in its arguments; per-call options travel in `ofmk_opts`
- *     (NULL = defaults).  Two host threads may drive two engines (own workspace, own stream,
+ *     (NULL = defaults), the LAST argument of EVERY compute entry point (ABI 3; only the
+ *     bandwidth probes and the timing-object functions at the end of this file take none).  Two host threads may drive two engines (own workspace, own stream,
  *     own timing object) concurrently (tests/test_gpu_parity.py::test_two_threads_two_engines);
  *   - return value 0 = OK, negative = error (OFMK_E_*); ofmk_last_error() gives the text for
  *     the calling thread; nothing throws across this boundary;
@@ -34,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OFMK_ABI_VERSION 2
+#define OFMK_ABI_VERSION 3
 
 #define OFMK_OK            0
 #define OFMK_E_ARG        -1   /* null pointer / non-positive size / H or W < 8 */
@@ -68,7 +69,10 @@ size_t ofmk_workspace_bytes(int frames_in_flight, int H, int W);
  *   in, out   device u8 [n][H][W][3]; out may alias in (in-place)
  *   wm        device u8 [n_wm][N] of 0/1, N = H*W/64 (DctEncoder.read_wm keeps row 0 of the
  *             generator's (1,N) array; n_wm > 1 lets segments carry different payloads)
- *   wm_row    device int32 [n] giving the wm row of each frame, or NULL = row 0 for all
+ *   wm_row    device int32 [n] giving the wm row of each frame, or NULL = row 0 for all.  The
+ *             reference has one watermark per encoder (dct_encoder.py:10-11); the row map is this
+ *             build's extension and so is its safety: the kernels clamp every entry into
+ *             [0, n_wm) (an out-of-range entry reads the nearest valid row, never out of bounds)
  *   alpha     DctEncoder(alpha=20)
  *   chunk_frames  frames per internal chunk, 0 = as many as the workspace holds            */
 int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
@@ -93,7 +97,8 @@ int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha
  * added before thresholding at 0 (offmark.dist.vote.soft_vote).  The reference's hard decision stays the
  * default everywhere. */
 int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha, long long *soft,
-                          int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+                          int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                          const ofmk_opts *opts);
 
 /* ---- embed then detect the produced frames, chunk by chunk (mark + verify) ---------------
  * The shape of tests/mark_video_to_hls.py:356-389 (verify every marked copy).  Same results as
@@ -113,7 +118,9 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
  *   scales   HOST array of 3 doubles, one per YUV channel as in DwtDctSvdEncoder(scales=[0,15,0])
  *            (dwt_dct_svd_encoder.py:6,19-26): every channel with a positive scale is marked with the same
  *            watermark; the read-out is channel 1's (dwt_dct_svd_decoder.py:24 returns wm_bits[1]), so
- *            detection with scales[1] <= 0 yields zeros, as in the reference.
+ *            detection with scales[1] <= 0 yields zeros, as in the reference.  A positive scale must be a normal
+ *            float32 >= 1e-3 after conversion (smaller steps are below the float32 resolution of typical top
+ *            singular values; rejected with OFMK_E_ARG), NaN / infinities are rejected.
  * Same frame/watermark/counts/bits conventions as the DCT entry points; no workspace (this codec has no
  * frame-global dependency: one pass).                                                            */
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
@@ -126,8 +133,10 @@ int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, in
                                int L, int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
 /* plugin level, float32 YUV [n][H][W][3] (n <= 65535): encode mutates the marked channels; decode fills bits */
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W,
-                           const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, void *stream);
-int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream);
+                           const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, void *stream,
+                           const ofmk_opts *opts);
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream,
+                           const ofmk_opts *opts);
 
 /* ---- planar 8-bit YUV 4:2:0 on either side of the DCT codec ------------------------------
  * The reference moves rgb24 over pipes and has ffmpeg convert to yuv420p on the way out
@@ -154,25 +163,29 @@ int ofmk_embed_detect_yuv420(const uint8_t *in, uint8_t *out, int layout, int n,
                              const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
                              int L, int32_t *counts, uint8_t *bits,
                              int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
-int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int H, int W, void *stream);
-int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int H, int W, void *stream);
+int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int H, int W, void *stream,
+                        const ofmk_opts *opts);
+int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int H, int W, void *stream,
+                        const ofmk_opts *opts);
 
 /* ---- DeShuffler.degenerate's epilogue for a batch, on the device ---------------------------
  * src/offmark/degenerator/de_shuffler.py:17-22: mean of bits[i::L] (from `counts`), undo the key
  * permutation (`perm` = DeShuffler.payload_idx, device int32 [L]), threshold strictly above the
  * mid-range of the L means.  payload: device u8 [n][L].  n_bits = H*W/64.                   */
 int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm,
-                              uint8_t *payload, void *stream);
+                              uint8_t *payload, void *stream, const ofmk_opts *opts);
 
 /* ---- plugin-level entry points on float32 YUV frames --------------------------------------
  * DctEncoder.encode(yuv) (dct_encoder.py:18-39; mutates channel 1 in place) and
  * DctDecoder.decode(yuv) (dct_decoder.py:10-27).  yuv: device f32 [n][H][W][3].            */
 int ofmk_encode_yuv32f(float *yuv, int n, int H, int W,
                        const uint8_t *wm, int n_wm, const int32_t *wm_row, double alpha,
-                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                       const ofmk_opts *opts);
 int ofmk_decode_yuv32f(const float *yuv, int n, int H, int W, int L, double alpha,
                        int32_t *counts, uint8_t *bits,
-                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream);
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                       const ofmk_opts *opts);
 
 /* ---- parity / debug planes for ONE frame (any pointer may be NULL) -----------------------
  * DctEncoder.luminance_mask / texture_mask (dct_encoder.py:41-102) and the [2][1] coefficient
@@ -183,7 +196,7 @@ int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double
                       const uint8_t *wm,
                       float *y_dc, double *lum_mask, double *tex_mask, double *step,
                       float *c21_pre, float *c21_post,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts);
 
 /* ---- individual stages (bench.py and tests drive single kernels with these) ----------------
  * analyze : frames -> per-block records (the kernel shared by embed and detect)

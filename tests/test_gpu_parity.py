@@ -686,7 +686,7 @@ def test_long_and_oversized_payloads_and_empty_inputs(eng):
     assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 0, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s, None) == -1
     assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, _hip.scales3(0), s, None) == -1
     assert lib.ofmk_svd_detect_rgb8(f.data_ptr(), 1, H, W, 8, _hip.scales3(15), None, None, s, None) == -1
-    assert lib.ofmk_payloads_from_counts(None, 1, 8, N, None, None, s) == -1
+    assert lib.ofmk_payloads_from_counts(None, 1, 8, N, None, None, s, None) == -1
     unaligned = torch.empty(ws.numel() + 1, dtype=torch.uint8, device="cuda")[1:]
     assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 20.0, 0, unaligned.data_ptr(), ws.numel(), s, None) == -1
     assert b"256-byte aligned" in lib.ofmk_last_error()

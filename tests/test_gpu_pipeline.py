@@ -212,3 +212,58 @@ def test_engine_refuses_a_bad_destination(eng):
         eng.embed_yuv420(planes, H, W, wm, out=torch.empty_like(planes).cpu())
     with pytest.raises(ValueError, match="unknown 4:2:0 layout"):
         eng.embed_yuv420(planes, H, W, wm, layout="yv12")
+
+
+def test_out_of_range_device_row_map_is_clamped_never_read_out_of_bounds(eng):
+    """the per-frame watermark-row map is this build's extension (the reference has one watermark per
+    encoder, dct_encoder.py:10-11), so its safety is too.  A DEVICE-resident map is not inspected on the host (that would
+    synchronise); the kernels clamp every entry into [0, n_wm): negative and too-large entries read the last row.  The
+    table is the last allocation made here and the bad entries point megabytes away from it -- an unclamped read would
+    fault or mark garbage.  With debug checks on, the host refuses the map."""
+    import torch
+    from offmark.engine import DctEngine
+    f = cuda(frames_rgb(4))
+    N = H * W // 64
+    rng = np.random.default_rng(3)
+    table = cuda(rng.integers(0, 2, (2, N), dtype=np.uint8))
+    bad = torch.tensor([-1, 1 << 20, 1, -(1 << 30)], dtype=torch.int32, device="cuda")
+    clamped = np.array([1, 1, 1, 1], np.int32)
+    for call in (lambda r: eng.embed(f, table, wm_row=r),
+                 lambda r: eng.svd_embed(f, table, wm_row=r),
+                 lambda r: eng.embed_detect(f, table, 8, wm_row=r)[0],
+                 lambda r: eng.svd_embed_detect(f, table, 8, wm_row=r)[0],
+                 lambda r: eng.embed_yuv420(eng.rgb_to_yuv420(f), H, W, table, wm_row=r),
+                 lambda r: eng.encode_yuv(f.float(), table, wm_row=r)):
+        got, want = call(bad), call(clamped)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError, match="wm_row entries"):
+        eng.embed(f, table, wm_row=bad.cpu().numpy())                 # host maps are always checked
+    strict = DctEngine()
+    strict.debug_checks = True
+    with pytest.raises(ValueError, match="wm_row entries"):
+        strict.embed(f, table, wm_row=bad)
+    assert torch.equal(strict.embed(f, table, wm_row=torch.tensor([0, 1, 1, 0], dtype=torch.int32, device="cuda")),
+                       eng.embed(f, table, wm_row=[0, 1, 1, 0]))
+
+
+def test_timing_options_do_not_dangle(eng):
+    """an Opts made by Timing.opts() keeps the pool alive and is disarmed by Timing.close()."""
+    import gc
+    from offmark import _hip
+    from offmark.engine import DctEngine
+    f = cuda(frames_rgb(2))
+    wm = np.zeros((1, H * W // 64), np.uint8)
+    timing = _hip.Timing(8)
+    e = DctEngine(opts=timing.opts())
+    e.embed(f, wm)
+    assert timing.collect()["analyze"]["launches"] == 1
+    timing.close()                                # the engine still holds the options: they no longer name the pool
+    assert not e.opts.timing
+    e.embed(f, wm)
+    e2 = DctEngine(opts=_hip.Timing(8).opts())    # the Timing object itself is dropped here ...
+    gc.collect()
+    e2.embed(f, wm)                               # ... but lives on through the options
+    assert e2.opts._timing.collect()["mark"]["launches"] == 1
+    import torch
+    torch.cuda.synchronize()

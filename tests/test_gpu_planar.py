@@ -138,7 +138,7 @@ def test_planar_argument_checks(eng):
     assert b"multiples of 8" in lib.ofmk_last_error()
     assert lib.ofmk_embed_yuv420(buf.data_ptr(), buf.data_ptr(), 2, 1, 16, 16, *args) == -1      # unknown layout
     assert lib.ofmk_embed_yuv420(buf.data_ptr() + 1, buf.data_ptr(), 0, 1, 16, 16, *args) == -1  # unaligned
-    assert lib.ofmk_yuv420_to_rgb8(None, buf.data_ptr(), 0, 1, 16, 16, s) == -1
+    assert lib.ofmk_yuv420_to_rgb8(None, buf.data_ptr(), 0, 1, 16, 16, s, None) == -1
     with pytest.raises(ValueError):
         eng.embed_yuv420(buf[: 16 * 16 * 3 // 2].view(1, -1)[:, :-8], 16, 16, np.zeros((1, 4)))
 

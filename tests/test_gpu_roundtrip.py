@@ -1,0 +1,164 @@
+"""The reference's own round-trip harness, JPEG leg included (reference tests/test.py:59-123):
+
+    image -> BGR2YUV -> generate_wm -> encode -> YUV2BGR -> clip -> around -> u8 -> cv2.imwrite(JPEG)
+          -> cv2.imread -> BGR2YUV -> decode -> degenerate
+
+for the generator:coder combinations upstream lists that are in scope (tests/test.py:59): 0:0 Shuffler x DwtDctSvd,
+0:3 Shuffler x Dct, 1:0 GrayScale(qr.jpeg) x DwtDctSvd, 1:3 GrayScale(qr.jpeg) x Dct -- on the reference's own
+frame63.jpeg, through the product's plugin classes on the GPU, and a segment-level version of it (8 segments x 12
+frames, every frame through a JPEG, per-segment Counter vote, tests/segment_mark_detect_hls.py:126-155 and its 75 %
+bar at :500) as a build-defined stand-in for the x264 leg (no ffmpeg here).
+
+The JPEG is the only "attack" upstream.  OpenCV is not installed, so Pillow writes and reads it: quality 95 and 4:2:0
+chroma subsampling, OpenCV's imwrite defaults (libjpeg in both; PARITY UNPINNED as far as the two libraries'
+encoders differ).  What is compared: the GPU's read-out of the decoded JPEG bytes against the ORACLE's read-out of the
+SAME bytes -- payload equal, raw bits within the budget over blocks whose decision is defined to float32 accuracy --
+and, where the oracle itself recovers the payload through the JPEG, that the GPU does too.
+(Measured with the oracle, frame63.jpeg, q95 4:2:0: raw bit error 11.5 % DwtDctSvd / 25.3 % Dct, 8-bit payload exact
+for both; the 21x21 qr image exact with DwtDctSvd, 95.7 % of its pixels with Dct.  At q75 nothing survives.)
+"""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import offmark_oracle as orc
+from conftest import GOLDEN, natural_frame
+
+pytestmark = pytest.mark.gpu
+P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+JPEG_QUALITY, JPEG_SUBSAMPLING = 95, 2            # cv2.imwrite defaults: quality 95, 4:2:0 (Pillow: subsampling=2)
+BITS_FRAC = 1e-4                                  # tests/test_gpu_parity.py's raw-bit budget
+
+
+def jpeg_round_trip(bgr, quality=JPEG_QUALITY, subsampling=JPEG_SUBSAMPLING):
+    """cv2.imwrite(path.jpeg, bgr); cv2.imread(path.jpeg) with Pillow: a true-colour JPEG of a BGR array."""
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(bgr[..., ::-1])).save(buf, format="JPEG", quality=quality, subsampling=subsampling)
+    return np.ascontiguousarray(np.array(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))[..., ::-1])
+
+
+def qr_payload():
+    return np.load(os.path.join(GOLDEN, "frame63_crop_qr_k0_a20.npz"))["payload"]      # the reference's qr.jpeg as grayscale
+
+
+def budget(n, frac, floor=1):
+    return max(floor, int(np.floor(n * frac)))
+
+
+def make(gen_idx, coder_idx):
+    """generators[gen_idx], degenerators[gen_idx], encoders[coder_idx], decoders[coder_idx] of tests/test.py:31-57,
+    product classes and their oracles."""
+    from offmark.degenerator.de_grayscale import DeGrayScale
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.embed.dct_encoder import DctEncoder
+    from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder
+    from offmark.extract.dct_decoder import DctDecoder
+    from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder
+    from offmark.generator.grayscale import GrayScale
+    from offmark.generator.shuffler import Shuffler
+    gen, deg = (Shuffler(key=0), DeShuffler(key=0)) if gen_idx == 0 else (GrayScale(key=0), DeGrayScale(key=0))
+    if coder_idx == 0:
+        return gen, deg, DwtDctSvdEncoder(), DwtDctSvdDecoder(), orc.DwtDctSvdEncoderOracle(), orc.DwtDctSvdDecoderOracle()
+    return gen, deg, DctEncoder(), DctDecoder(), orc.DctEncoderOracle(), orc.DctDecoderOracle()
+
+
+def determined_blocks(dec_oracle, coder_idx, shape):
+    """Blocks whose read-out is defined to float32 accuracy (after a JPEG the decision variable lands anywhere, also
+    on its thresholds): Dct -- C21/step at least 1e-4 away from a half-integer; DwtDctSvd -- s0 mod 15 at least
+    2e-6*s0 + 1e-5 away from 0, 7.5 and 15 (the stand-alone read-out solves s0 to 4.6e-7 relative, csrc/svd_kernels.hiph)."""
+    h8, w8 = shape[0] // 8, shape[1] // 8
+    if coder_idx == 3:
+        r = dec_oracle.debug["c21"].astype(np.float64) / (dec_oracle.alpha * dec_oracle.debug["mask"])
+        ok = np.abs(np.abs(r - np.floor(r)) - 0.5) > 1e-4
+    else:
+        s0 = dec_oracle.debug["s0"].astype(np.float64)
+        m = np.mod(s0, 15.0)
+        ok = np.minimum(np.minimum(m, 15.0 - m), np.abs(m - 7.5)) > 2e-6 * s0 + 1e-5
+    return ok.reshape(-1)[: h8 * w8]
+
+
+@pytest.mark.parametrize("gen_idx,coder_idx", [(0, 0), (0, 3), (1, 0), (1, 3)])
+def test_reference_round_trip_harness_with_jpeg(gen_idx, coder_idx):
+    from offmark.video.color import bgr2yuv, yuv2bgr
+    img = np.ascontiguousarray(natural_frame()[..., ::-1])              # cv2.imread order: BGR
+    payload = P8 if gen_idx == 0 else qr_payload()
+    generator, degenerator, encoder, decoder, enc_o, dec_o = make(gen_idx, coder_idx)
+    assert generator.wm_type() == ("bits" if gen_idx == 0 else "grayscale")
+    # -- tests/test.py:85-99, literally, through the float32 plugin boundary
+    yuv = bgr2yuv(img.astype(np.float32))
+    wm = generator.generate_wm(payload, encoder.wm_capacity(yuv.shape))
+    encoder.read_wm(wm)
+    yuv = encoder.encode(yuv)
+    wmed = np.around(np.clip(yuv2bgr(yuv), a_min=0, a_max=255)).astype(np.uint8)
+    # the batch path of the same classes (u8 in, u8 out: what Embedder uses) marks the same pixels
+    import torch
+    fast = encoder.encode_frames_u8(torch.from_numpy(img[None]).cuda())[0].cpu().numpy()
+    d = np.abs(fast.astype(int) - wmed.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())     # float32 YUV frame in memory vs fused registers
+    # -- :99,111  cv2.imwrite / cv2.imread
+    rx = jpeg_round_trip(wmed)
+    assert rx.shape == img.shape and (rx != wmed).mean() > 0.05                 # a lossy leg, not a no-op
+    # -- :113-121 decode, degenerate
+    decoded_wm = decoder.decode(bgr2yuv(rx.astype(np.float32)))
+    ret_payload = degenerator.set_shape(payload.shape).degenerate(decoded_wm)
+    # the oracle on the SAME decoded bytes
+    ref_bits = orc.check_frame(rx, dec_o)
+    ref_payload = orc.deshuffle(ref_bits, 8, 0) if gen_idx == 0 else orc.degrayscale(ref_bits, payload.shape, 0)
+    ok = determined_blocks(dec_o, coder_idx, img.shape)
+    n = ok.size
+    mism = (decoded_wm.reshape(-1)[:n] != ref_bits.reshape(-1)[:n])
+    assert ok.mean() > 0.995
+    assert mism[ok].sum() <= budget(int(ok.sum()), BITS_FRAC), (int(mism[ok].sum()), int(mism.sum()), n)
+    assert np.array_equal(ret_payload, ref_payload)
+    # and the u8 batch read-out (what Extractor uses) agrees with the plugin-boundary one
+    counts, bits = decoder.decode_frames_u8(torch.from_numpy(rx[None]).cuda(), int(np.prod(payload.shape)), want_bits=True)
+    assert (bits[0].cpu().numpy()[:n] != decoded_wm.reshape(-1)[:n])[ok].sum() <= budget(int(ok.sum()), BITS_FRAC)
+    assert np.array_equal(degenerator.degenerate_counts(counts.cpu().numpy(), img.shape[0] * img.shape[1] // 64)[0], ret_payload)
+    # what the oracle recovers through the JPEG, the GPU recovers
+    want = payload if gen_idx == 0 else ((payload > 127) * 255).astype(np.uint8)
+    agree = float((ret_payload == want).mean())
+    if (gen_idx, coder_idx) != (1, 3):
+        assert agree == 1.0                      # measured with the oracle: exact for 0:0, 0:3, 1:0
+    else:
+        assert agree > 0.93                      # 441 image bits x 73 repeats at 25 % raw bit error: oracle 95.7 %
+
+
+@pytest.mark.parametrize("codec", ["dwtdctsvd", "dct"])
+def test_segments_through_per_frame_jpeg_and_the_75_percent_bar(codec):
+    """8 segments x 12 frames of natural content (640x360 windows sliding over frame63.jpeg), segment s carries
+    format(s + 1, '08b') (tests/segment_mark_detect_hls.py:42-55; numbering from 1: the all-zero payload cannot be
+    decoded by the mid-range threshold), every marked frame goes through a JPEG (quality 95, 4:2:0), then detect,
+    per-segment Counter vote, preserved-segment rate against the reference's 75 % bar (:500).  Every frame's payload
+    is also compared with the oracle's read-out of the same decoded bytes."""
+    import torch
+    from offmark import fingerprint as fp
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.dist.vote import vote_segments
+    from offmark.engine import DctEngine
+    from offmark.generator.shuffler import Shuffler
+    S, F, h, w = 8, 12, 360, 640
+    nat = natural_frame()
+    frames = np.stack([nat[40 + 60 * (i // F) + 3 * (i % F):, 16 * (i % F) + 100 * (i // F):][:h, :w] for i in range(S * F)])
+    assert frames.shape == (S * F, h, w, 3)
+    N = h * w // 64
+    payloads = np.stack([fp.payload_for_segment(s + 1) for s in range(S)])
+    table = np.stack([Shuffler(key=0).generate_wm(p, (1, N))[0] for p in payloads]).astype(np.uint8)
+    rows = np.repeat(np.arange(S), F).astype(np.int32)
+    eng = DctEngine()
+    dev = torch.from_numpy(frames).cuda()
+    marked = (eng.embed(dev, table, wm_row=rows) if codec == "dct" else eng.svd_embed(dev, table, wm_row=rows)).cpu().numpy()
+    rx = np.stack([jpeg_round_trip(f) for f in marked])
+    counts, _ = eng.detect(torch.from_numpy(rx).cuda(), 8) if codec == "dct" else eng.svd_detect(torch.from_numpy(rx).cuda(), 8)
+    deg = DeShuffler(key=0).set_shape((8,))
+    got = deg.degenerate_counts(counts.cpu().numpy(), N)
+    dec_o = orc.DctDecoderOracle() if codec == "dct" else orc.DwtDctSvdDecoderOracle()
+    ref = np.stack([orc.deshuffle(orc.check_frame(f, dec_o), 8, 0) for f in rx])
+    assert np.array_equal(got, ref)                                    # frame by frame, the oracle's payloads
+    votes = vote_segments(got, np.repeat(np.arange(S), F))
+    preserved = sum(int(np.array_equal(votes[s][0], payloads[s])) for s in range(S))
+    frame_rate = float((got == payloads[rows]).all(axis=1).mean())
+    print(f"{codec}: segments preserved {preserved}/{S}, frames with exact payload {frame_rate:.3f}")
+    assert preserved / S >= 0.75                                       # tests/segment_mark_detect_hls.py:500

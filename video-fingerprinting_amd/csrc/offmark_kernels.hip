@@ -227,7 +227,7 @@ int launch_finalize(FinArgs a, int n, const Ctx &cx) {
 
 // Needs the input frames' records in ws.rec / ws.ysum (launch_analyze).  fused = true also leaves the
 // MARKED frames' records in ws.rec and their mean accumulators in ws.ysum2.
-int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
+int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
                      double alpha, const Workspace &ws, bool fused, const Ctx &cx, bool ysum2_is_zero = false) {
     hipStream_t s = cx.s;
     if (fused && !ysum2_is_zero) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
@@ -239,6 +239,7 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
     m.ysum = ws.ysum;
     m.wm = wm;
     m.wm_row = wm_row;
+    m.n_wm = n_wm;
     m.N = (int)((long long)H * W / 64);
     m.alpha = alpha;
     {
@@ -268,6 +269,7 @@ FinArgs fin_base(const Workspace &ws, int H, int W, double alpha) {
     a.nblk = (H / 8) * (W / 8);
     a.N = (int)((long long)H * W / 64);
     a.L = 1;
+    a.n_wm = 1;
     a.alpha = alpha;
     return a;
 }
@@ -284,7 +286,7 @@ int finalize_detect(int f0, int cf, int H, int W, int L, double alpha, int32_t *
 
 // analyze + mark for frames [f0, f0+cf); verify = also leave the marked frames' records in the
 // workspace (fused kernel), ready for finalize_detect(after_fused_mark = true)
-int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W, const uint8_t *wm,
+int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W, const uint8_t *wm, int n_wm,
                 const int32_t *wm_row, double alpha, const Workspace &ws, bool verify, const Ctx &s,
                 int32_t *zero_counts = nullptr, int L = 0) {
     const size_t fs = (size_t)H * W * 3;
@@ -295,12 +297,13 @@ int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W
     if (rc) return rc;
     const int32_t *rows = wm_row ? wm_row + f0 : nullptr;
     if (src == SRC_RGB8)
-        return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, wm,
+        return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, wm, n_wm,
                                 rows, alpha, ws, verify, s, /*ysum2_is_zero=*/true);   // by launch_analyze just above
     // float32 YUV plugin path: separate scalar stage, then the rank-1 update of channel 1
     FinArgs a = fin_base(ws, H, W, alpha);
     a.wm = wm;
     a.wm_row = rows;
+    a.n_wm = n_wm;
     a.delta = ws.delta;
     if ((rc = launch_finalize(a, cf, s))) return rc;
     const Geom g = make_geom(H, W, ws);
@@ -337,7 +340,7 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
         if (b.bits) b.bits += (size_t)f0 * a.N;
         const dim3 grid = block_grid(g, cf);
         ScopedTiming timing(KIND_SVD, cx);
-#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), OFMK_SVD_LDS_CAP, s, in + fo, out ? out + fo : nullptr, g, b)
+#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
         const bool multi = a.scales[0] > 0.f || a.scales[2] > 0.f || !(a.scales[1] > 0.f);      // anything but the default [0, s, 0]
         if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT, false); else OFMK_SVD_LAUNCH(false, SVD_DETECT, false); }
         else if (mode == SVD_EMBED && !multi) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED, false); else OFMK_SVD_LAUNCH(false, SVD_EMBED, false); }
@@ -388,7 +391,7 @@ int launch_analyze_yuv420(const uint8_t *frames, int layout, int n, int H, int W
     return OFMK_OK;
 }
 
-int launch_mark_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, const int32_t *wm_row,
+int launch_mark_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
                        double alpha, const Workspace &ws, bool fused, const Ctx &cx) {
     const PGeom g = make_pgeom(layout, H, W, ws.plane);
     const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);
@@ -397,6 +400,7 @@ int launch_mark_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H
     m.ysum = ws.ysum;
     m.wm = wm;
     m.wm_row = wm_row;
+    m.n_wm = n_wm;
     m.N = (int)((long long)H * W / 64);
     m.alpha = alpha;
     ScopedTiming timing(KIND_PLANAR, cx);
@@ -416,9 +420,13 @@ int set_scales(SvdArgs &a, const double *scales, bool need_channel1) {
     if (!scales) return fail(OFMK_E_ARG, "scales is null (host array of 3 doubles)%s");
     bool any = false;
     for (int k = 0; k < 3; ++k) {
-        if (!(scales[k] == scales[k]) || scales[k] > 1e30) return fail(OFMK_E_ARG, "scales must be finite%s");
-        a.scales[k] = scales[k] > 0 ? (float)scales[k] : 0.f;
-        any |= scales[k] > 0;
+        if (!(scales[k] == scales[k]) || scales[k] > 1e30 || scales[k] < -1e30) return fail(OFMK_E_ARG, "scales must be finite%s");
+        // decided on the float32 value the kernels use: a positive scale that is no normal float32 >= 1e-3 would mark
+        // nothing (flushed to 0) or feed denormals to the quotient / remainder arithmetic
+        const float sc = scales[k] > 0 ? (float)scales[k] : 0.f;
+        if (scales[k] > 0 && !(sc >= 1.0e-3f)) return fail(OFMK_E_ARG, "a positive scale must be >= 1e-3 as float32%s");
+        a.scales[k] = sc;
+        any |= sc > 0.f;
     }
     if (!any && !need_channel1) return fail(OFMK_E_ARG, "no channel has a positive scale%s");
     return OFMK_OK;
@@ -464,7 +472,7 @@ int ofmk_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const 
     const Ctx cx = make_ctx(stream, opts);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, cx))) return rc;
+        if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, n_wm, wm_row, alpha, ws, false, cx))) return rc;
     }
     return OFMK_OK;
 }
@@ -488,14 +496,15 @@ int ofmk_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha
 // of -cos(pi * C21/step) in 2^14 fixed point (positive = the position reads as 1).  One histogram per call, so
 // it is a separate entry point from the hard-decision counts.
 int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double alpha, long long *soft, int chunk_frames,
-                          void *workspace, size_t workspace_bytes, void *stream) {
+                          void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!in || !soft) return fail(OFMK_E_ARG, "null pointer%s");
     if (L < 1) return fail(OFMK_E_ARG, "payload length L must be >= 1%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    const Ctx cx = make_ctx(stream, nullptr);
+    const Ctx cx = make_ctx(stream, opts);
     HIP_TRY(hipMemsetAsync(soft, 0, (size_t)n * L * sizeof(long long), cx.s));
     const size_t fs = (size_t)H * W * 3;
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
@@ -523,10 +532,10 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         if (!(cx.flags & OFMK_F_SEPARATE_DETECT)) {
-            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, true, cx, counts, L))) return rc;
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, n_wm, wm_row, alpha, ws, true, cx, counts, L))) return rc;
             if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, cx))) return rc;
         } else {
-            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, wm_row, alpha, ws, false, cx))) return rc;
+            if ((rc = embed_chunk(in, out, SRC_RGB8, f0, cf, H, W, wm, n_wm, wm_row, alpha, ws, false, cx))) return rc;
             if ((rc = detect_chunk(out, SRC_RGB8, f0, cf, H, W, L, alpha, counts, bits, ws, cx))) return rc;
         }
     }
@@ -534,26 +543,29 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
 }
 
 int ofmk_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
-                       double alpha, int chunk_frames, void *workspace, size_t workspace_bytes, void *stream) {
+                       double alpha, int chunk_frames, void *workspace, size_t workspace_bytes, void *stream,
+                       const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(yuv, yuv, n, H, W, wm, n_wm);
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    const Ctx cx = make_ctx(stream, nullptr);
+    const Ctx cx = make_ctx(stream, opts);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
-        if ((rc = embed_chunk(yuv, yuv, SRC_YUV32F, f0, cf, H, W, wm, wm_row, alpha, ws, false, cx))) return rc;
+        if ((rc = embed_chunk(yuv, yuv, SRC_YUV32F, f0, cf, H, W, wm, n_wm, wm_row, alpha, ws, false, cx))) return rc;
     }
     return OFMK_OK;
 }
 
 int ofmk_decode_yuv32f(const float *yuv, int n, int H, int W, int L, double alpha, int32_t *counts, uint8_t *bits,
-                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream) {
+                       int chunk_frames, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_detect_args(yuv, n, H, W, L, counts, bits);
     if (rc) return rc;
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
-    const Ctx cx = make_ctx(stream, nullptr);
+    const Ctx cx = make_ctx(stream, opts);
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         if ((rc = detect_chunk(yuv, SRC_YUV32F, f0, cf, H, W, L, alpha, counts, bits, ws, cx))) return rc;
@@ -563,14 +575,15 @@ int ofmk_decode_yuv32f(const float *yuv, int n, int H, int W, int L, double alph
 
 int ofmk_debug_planes(const void *frame, int src_is_yuv32f, int H, int W, double alpha, const uint8_t *wm,
                       float *y_dc, double *lum_mask, double *tex_mask, double *step, float *c21_pre,
-                      float *c21_post, void *workspace, size_t workspace_bytes, void *stream) {
+                      float *c21_post, void *workspace, size_t workspace_bytes, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(1, H, W);
     if (rc) return rc;
     if (!frame) return fail(OFMK_E_ARG, "null frame pointer%s");
     if (c21_post && !wm) return fail(OFMK_E_ARG, "c21_post requested without a watermark%s");
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, 1, ws))) return rc;
-    const Ctx cx = make_ctx(stream, nullptr);
+    const Ctx cx = make_ctx(stream, opts);
     if ((rc = launch_analyze(frame, src_is_yuv32f ? SRC_YUV32F : SRC_RGB8, 1, H, W, ws, cx))) return rc;
     FinArgs a = fin_base(ws, H, W, alpha);
     a.wm = wm;
@@ -603,7 +616,7 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, c
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, n, ws))) return rc;
     if (ws.frames < n) return fail(OFMK_E_WORKSPACE, "stage call needs workspace for all n frames%s");
-    return launch_mark_rgb8(in, out, n, H, W, wm, nullptr, alpha, ws, fused != 0, make_ctx(stream, opts));
+    return launch_mark_rgb8(in, out, n, H, W, wm, 1, nullptr, alpha, ws, fused != 0, make_ctx(stream, opts));
 }
 
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
@@ -614,7 +627,7 @@ int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, co
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
-    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1;
+    a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.N = (int)((long long)H * W / 64); a.L = 1;
     return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED, a, make_ctx(stream, opts));
 }
 
@@ -647,20 +660,21 @@ int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, in
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
-    a.wm = wm; a.wm_row = wm_row; a.counts = counts; a.bits = bits;
+    a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.counts = counts; a.bits = bits;
     a.N = (int)((long long)H * W / 64); a.L = L;
     return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
-                           const double *scales, void *stream) {
+                           const double *scales, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(yuv, yuv, n, H, W, wm, n_wm);
     if (rc) return rc;
     if (n > kMaxChunk) return fail(OFMK_E_ARG, "too many frames%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
-    a.wm = wm; a.wm_row = wm_row; a.N = (int)((long long)H * W / 64); a.L = 1;
+    a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.N = (int)((long long)H * W / 64); a.L = 1;
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
@@ -669,7 +683,9 @@ int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, i
     return OFMK_OK;
 }
 
-int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream) {
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream,
+                           const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!yuv || !bits) return fail(OFMK_E_ARG, "null pointer%s");
@@ -690,7 +706,8 @@ int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *
 }
 
 int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm, uint8_t *payload,
-                              void *stream) {
+                              void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     if (!counts || !perm || !payload) return fail(OFMK_E_ARG, "null pointer%s");
     if (n < 1 || L < 1 || n_bits < 0) return fail(OFMK_E_ARG, "bad sizes%s");
     hipLaunchKernelGGL(degenerate_kernel, dim3((unsigned)n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), counts,
@@ -714,7 +731,7 @@ int ofmk_embed_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H,
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
         if ((rc = launch_analyze_yuv420(in + (size_t)f0 * fs, layout, cf, H, W, ws, cx))) return rc;
-        if ((rc = launch_mark_yuv420(in + (size_t)f0 * fs, out + (size_t)f0 * fs, layout, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr,
+        if ((rc = launch_mark_yuv420(in + (size_t)f0 * fs, out + (size_t)f0 * fs, layout, cf, H, W, wm, n_wm, wm_row ? wm_row + f0 : nullptr,
                                      alpha, ws, false, cx))) return rc;
     }
     return OFMK_OK;
@@ -757,7 +774,7 @@ int ofmk_embed_detect_yuv420(const uint8_t *in, uint8_t *out, int layout, int n,
         uint8_t *pout = out + (size_t)f0 * fs;
         int32_t *zc = counts ? counts + (size_t)f0 * L : nullptr;
         if ((rc = launch_analyze_yuv420(pin, layout, cf, H, W, ws, cx, fused ? zc : nullptr, L))) return rc;
-        if ((rc = launch_mark_yuv420(pin, pout, layout, cf, H, W, wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, fused, cx))) return rc;
+        if ((rc = launch_mark_yuv420(pin, pout, layout, cf, H, W, wm, n_wm, wm_row ? wm_row + f0 : nullptr, alpha, ws, fused, cx))) return rc;
         if (fused) {
             if ((rc = finalize_detect(f0, cf, H, W, L, alpha, counts, bits, ws, true, cx))) return rc;
         } else {
@@ -768,7 +785,8 @@ int ofmk_embed_detect_yuv420(const uint8_t *in, uint8_t *out, int layout, int n,
     return OFMK_OK;
 }
 
-int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int H, int W, void *stream) {
+int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int H, int W, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!yuv || !rgb) return fail(OFMK_E_ARG, "null pointer%s");
@@ -787,7 +805,8 @@ int ofmk_yuv420_to_rgb8(const uint8_t *yuv, uint8_t *rgb, int layout, int n, int
     return OFMK_OK;
 }
 
-int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int H, int W, void *stream) {
+int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int H, int W, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(n, H, W);
     if (rc) return rc;
     if (!yuv || !rgb) return fail(OFMK_E_ARG, "null pointer%s");
@@ -813,17 +832,17 @@ int ofmk_timing_create(int max_launches, unsigned kind_mask, ofmk_timing **out) 
     if (max_launches < 1) return fail(OFMK_E_ARG, "max_launches must be positive%s");
     ofmk_timing *t = new ofmk_timing;
     t->rec = new TimingRec[max_launches];
-    t->cap = 0;
+    t->cap = max_launches;
     t->used.store(0);
     t->mask = kind_mask ? kind_mask : 0xFFFFFFFFu;
+    for (int i = 0; i < max_launches; ++i) { t->rec[i].a = nullptr; t->rec[i].b = nullptr; t->rec[i].kind = -1; }
     for (int i = 0; i < max_launches; ++i) {
         hipError_t e = hipEventCreate(&t->rec[i].a);
         if (e == hipSuccess) e = hipEventCreate(&t->rec[i].b);
         if (e != hipSuccess) {
-            ofmk_timing_destroy(t);
+            ofmk_timing_destroy(t);                 // destroys whichever events exist (the others are null)
             return fail(OFMK_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
-        t->cap = i + 1;
     }
     *out = t;
     return OFMK_OK;
@@ -834,20 +853,32 @@ int ofmk_timing_collect(ofmk_timing *t, double *ms_by_kind, int *launches_by_kin
     for (int k = 0; k < KIND_COUNT; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
     const int taken = t->used.load();
     const int used = taken < t->cap ? taken : t->cap;
+    int rc = OFMK_OK;
     for (int i = 0; i < used; ++i) {
-        HIP_TRY(hipEventSynchronize(t->rec[i].b));
+        // a pair whose launch failed after it was reserved was never recorded: skip it, do not poison the pool
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, t->rec[i].a, t->rec[i].b));
-        ms_by_kind[t->rec[i].kind] += ms;
-        launches_by_kind[t->rec[i].kind] += 1;
+        hipError_t e = hipEventSynchronize(t->rec[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, t->rec[i].a, t->rec[i].b);
+        if (e == hipSuccess && t->rec[i].kind >= 0 && t->rec[i].kind < KIND_COUNT) {
+            ms_by_kind[t->rec[i].kind] += ms;
+            launches_by_kind[t->rec[i].kind] += 1;
+        } else if (e != hipSuccess && e != hipErrorInvalidHandle && e != hipErrorInvalidResourceHandle && e != hipErrorNotReady) {
+            rc = fail(OFMK_E_HIP, "timing collect: %s", hipGetErrorString(e));
+        }
+        if (e != hipSuccess) (void)hipGetLastError();
+        t->rec[i].kind = -1;
     }
     t->used.store(0);
+    if (rc) return rc;
     return OFMK_OK;
 }
 
 void ofmk_timing_destroy(ofmk_timing *t) {
     if (!t) return;
-    for (int i = 0; i < t->cap; ++i) { (void)hipEventDestroy(t->rec[i].a); (void)hipEventDestroy(t->rec[i].b); }
+    for (int i = 0; i < t->cap; ++i) {
+        if (t->rec[i].a) (void)hipEventDestroy(t->rec[i].a);
+        if (t->rec[i].b) (void)hipEventDestroy(t->rec[i].b);
+    }
     delete[] t->rec;
     delete t;
 }

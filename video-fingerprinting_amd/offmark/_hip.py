@@ -12,12 +12,15 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liboffmark_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Opts(C.Structure):
-    """ofmk_opts: per-call options (flags, optional timing object).  None / NULL = defaults."""
+    """ofmk_opts: per-call options (flags, optional timing object).  None / NULL = defaults.
+    An Opts made by Timing.opts() keeps its Timing alive (``_timing``) and is invalidated by Timing.close(): its
+    pointer is nulled, so an engine that still holds it simply launches without events instead of touching freed memory."""
     _fields_ = [("flags", C.c_uint32), ("reserved", C.c_uint32), ("timing", C.c_void_p)]
+    _timing = None
 
 
 F_SEPARATE_DETECT = 1
@@ -35,26 +38,26 @@ SIGNATURES = {
     "ofmk_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "ofmk_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
     "ofmk_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),
-    "ofmk_detect_soft_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _sz, _vp]),
+    "ofmk_detect_soft_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _sz, _vp, _op]),
     "ofmk_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _i32, _vp, _sz,
                                       _vp, _op]),
-    "ofmk_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp]),
-    "ofmk_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp]),
-    "ofmk_debug_planes": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ofmk_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),
+    "ofmk_debug_planes": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _op]),
     "ofmk_stage_analyze_rgb8": (_i32, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _op]),
     "ofmk_stage_mark_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
     "ofmk_svd_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp, _op]),
     "ofmk_svd_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _dp, _vp, _vp, _vp, _op]),
     "ofmk_svd_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _vp, _vp, _vp, _op]),
-    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp]),
-    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _dp, _vp, _vp]),
-    "ofmk_payloads_from_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp, _op]),
+    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _dp, _vp, _vp, _op]),
+    "ofmk_payloads_from_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _op]),
     "ofmk_embed_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
     "ofmk_detect_yuv420": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),
     "ofmk_embed_detect_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _i32, _vp,
                                         _sz, _vp, _op]),
-    "ofmk_yuv420_to_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "ofmk_rgb8_to_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ofmk_yuv420_to_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _op]),
+    "ofmk_rgb8_to_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _op]),
     "ofmk_hbm_copy": (_i32, [_vp, _vp, _sz, _vp]),
     "ofmk_hbm_read": (_i32, [_vp, _sz, _vp, _vp]),
     "ofmk_timing_create": (_i32, [_i32, _u32, C.POINTER(_vp)]),
@@ -104,10 +107,15 @@ class Timing:
     def __init__(self, max_launches: int, kind_mask: int = 0):
         self.lib = load()
         self.handle = _vp()
+        self._handed_out = []
         check(self.lib.ofmk_timing_create(int(max_launches), int(kind_mask), C.byref(self.handle)))
 
     def opts(self, flags: int = 0) -> Opts:
-        return Opts(flags, 0, self.handle)
+        import weakref
+        o = Opts(flags, 0, self.handle)
+        o._timing = self                                  # the pool lives at least as long as the options that name it
+        self._handed_out.append(weakref.ref(o))
+        return o
 
     def collect(self) -> dict:
         ms = (_f64 * len(TIMING_KINDS))()
@@ -116,6 +124,11 @@ class Timing:
         return {k: dict(ms_total=ms[i], launches=cnt[i]) for i, k in enumerate(TIMING_KINDS)}
 
     def close(self):
+        for ref in self._handed_out:                      # options still held elsewhere stop naming the pool
+            o = ref()
+            if o is not None:
+                o.timing = None
+        self._handed_out = []
         if self.handle:
             self.lib.ofmk_timing_destroy(self.handle)
             self.handle = _vp()

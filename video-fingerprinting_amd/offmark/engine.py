@@ -35,6 +35,9 @@ class DctEngine:
         self.device = self.torch.device("cuda", self.torch.cuda.current_device()) if device is None \
             else self.torch.device(device)
         self.chunk_frames = chunk_frames
+        # range-check device-resident row maps too (costs a host synchronisation per call, so off by default; the kernels
+        # clamp every entry into [0, n_wm) either way -- include/offmark_hip.h)
+        self.debug_checks = os.environ.get("OFFMARK_DEBUG_CHECKS", "0") not in ("", "0")
         self._ws = {}
 
     # -- scratch ------------------------------------------------------------------------------
@@ -90,8 +93,9 @@ class DctEngine:
         return wm
 
     def _rows(self, wm_row, n, n_wm=None):
-        """Per-frame watermark-row map -> device int32 [n].  Host arrays are range-checked here; the kernels
-        index the watermark table with these values unchecked."""
+        """Per-frame watermark-row map -> device int32 [n].  Host arrays are always range-checked here, device tensors
+        when ``debug_checks`` is set (OFFMARK_DEBUG_CHECKS=1: it needs a synchronisation); the kernels clamp whatever
+        arrives into [0, n_wm), so a bad map marks with the wrong row but never reads out of bounds."""
         if wm_row is None:
             return None
         t = self.torch
@@ -101,8 +105,9 @@ class DctEngine:
             if n_wm is not None and wm_row.size and (wm_row.min() < 0 or wm_row.max() >= n_wm):
                 raise ValueError(f"wm_row entries must be in [0, {n_wm}); got [{wm_row.min()}, {wm_row.max()}]")
             wm_row = t.from_numpy(wm_row.astype(np.int32))
-        elif n_wm is not None and not wm_row.is_cuda and wm_row.numel() and (int(wm_row.min()) < 0 or int(wm_row.max()) >= n_wm):
-            raise ValueError(f"wm_row entries must be in [0, {n_wm})")
+        elif (n_wm is not None and (not wm_row.is_cuda or self.debug_checks) and wm_row.numel()
+              and (int(wm_row.min()) < 0 or int(wm_row.max()) >= n_wm)):
+            raise ValueError(f"wm_row entries must be in [0, {n_wm}); got [{int(wm_row.min())}, {int(wm_row.max())}]")
         wm_row = wm_row.to(device=self.device, dtype=t.int32).contiguous()
         if wm_row.numel() != n:
             raise ValueError("wm_row needs one entry per frame")
@@ -146,7 +151,7 @@ class DctEngine:
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_detect_soft_rgb8(frames.data_ptr(), n, H, W, int(L), float(alpha), soft.data_ptr(), cf,
-                                                  ws.data_ptr(), ws.numel(), _hip.current_stream()))
+                                                  ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return soft
 
     def embed_detect(self, frames, wm, L, alpha=20, wm_row=None, out=None, want_bits=False):
@@ -176,7 +181,7 @@ class DctEngine:
         if out is None:
             out = t.empty((n, L), dtype=t.uint8, device=self.device)
         _hip.check(self.lib.ofmk_payloads_from_counts(counts.data_ptr(), n, L, int(n_bits), perm.data_ptr(),
-                                                      out.data_ptr(), _hip.current_stream()))
+                                                      out.data_ptr(), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return out
 
     # -- planar 8-bit YUV 4:2:0 in and out (what a decoder hands over / an encoder takes) -----------
@@ -240,7 +245,7 @@ class DctEngine:
         n = self._check_planar(planes, H, W)
         rgb = self._out(out, planes, (n, H, W, 3))
         _hip.check(self.lib.ofmk_yuv420_to_rgb8(planes.data_ptr(), rgb.data_ptr(), self._layout(layout), n, H, W,
-                                                _hip.current_stream()))
+                                                _hip.current_stream(), _hip.opts_ref(self.opts)))
         return rgb
 
     def rgb_to_yuv420(self, frames, layout="i420", out=None):
@@ -250,7 +255,7 @@ class DctEngine:
             raise ValueError("planar 4:2:0 frames need H and W to be multiples of 8")
         planes = self._out(out, frames, (n, H * W * 3 // 2))
         _hip.check(self.lib.ofmk_rgb8_to_yuv420(frames.data_ptr(), planes.data_ptr(), self._layout(layout), n, H, W,
-                                                _hip.current_stream()))
+                                                _hip.current_stream(), _hip.opts_ref(self.opts)))
         return planes
 
     # -- float32 YUV path (the literal encode(yuv)/decode(yuv) plugin boundary) ------------------
@@ -262,7 +267,7 @@ class DctEngine:
         cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], _hip.ptr(rows),
-                                               float(alpha), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
+                                               float(alpha), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return yuv
 
     def decode_yuv(self, yuv, L=1, alpha=20, want_bits=True):
@@ -274,7 +279,7 @@ class DctEngine:
         cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_decode_yuv32f(yuv.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
-                                               _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream()))
+                                               _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return counts, bits
 
     # -- DwtDctSvd codec (one pass, no workspace) ---------------------------------------------------
@@ -317,7 +322,7 @@ class DctEngine:
         n, H, W = self._check_frames(yuv, t.float32)
         wm = self._wm(wm, H * W // 64)
         _hip.check(self.lib.ofmk_svd_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], None,
-                                                   _hip.scales3(scale, scales), _hip.current_stream()))
+                                                   _hip.scales3(scale, scales), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return yuv
 
     def svd_decode_yuv(self, yuv, scale=15, scales=None):
@@ -325,7 +330,7 @@ class DctEngine:
         n, H, W = self._check_frames(yuv, t.float32)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device)
         _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, _hip.scales3(scale, scales), bits.data_ptr(),
-                                                   _hip.current_stream()))
+                                                   _hip.current_stream(), _hip.opts_ref(self.opts)))
         return bits
 
     # -- parity planes ----------------------------------------------------------------------------
@@ -344,7 +349,7 @@ class DctEngine:
                                               _hip.ptr(wmt), ydc.data_ptr(), lum.data_ptr(), tex.data_ptr(),
                                               step.data_ptr(), c21_pre.data_ptr(),
                                               c21_post.data_ptr() if wmt is not None else None,
-                                              ws.data_ptr(), ws.numel(), _hip.current_stream()))
+                                              ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
         out = dict(y_dc=ydc, lum=lum, tex=tex, step=step, c21_pre=c21_pre)
         if wmt is not None:
             out["c21_post"] = c21_post
