@@ -1011,6 +1011,30 @@ def test_bench_configs_run_at_one_gpu(config, extra):
         assert line["pcie_inclusive"]["i420"]["frames_per_s"] > 0 and line["pcie_inclusive"]["rgb24"]["frames_per_s"] > 0
 
 
+def test_bench_config3_4k_at_a_stress_size():
+    """BASELINE.json configs[2] (4K, HBM-bound stress) at a size the driver's own test run sees: 200 frames of 3840x2160
+    per step = 5 GB in + 5 GB out, three internal chunks of the default 2 GiB.  Payloads exact; the path must hold
+    >= 0.55 of the 8 TB/s spec (measured 0.60, profiles/r2_bench_config3_4k_1000frames.json) in the timed region or in
+    the pass right after it (a 5-step timed region from idle sits on the clock ramp)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "3", "--frames", "200", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["payload_bit_exact"] and line["second_pass"]["votes_ok"] and line["config"]["frames_per_gpu"] == 200
+    assert line["config"]["chunk_frames"] < 200                     # several chunks
+    spec = 8000.0
+    timed = line["path"]["frac_of_peak"]
+    after = line["value_second_pass"] * line["path"]["bytes_per_frame"] / 1e9 / spec
+    print(f"config 3 at 200 frames: path {timed:.3f} of spec in the timed region, {after:.3f} in the second pass, "
+          f"{line['value']:.0f} frames/s, dominant kernel {line['roofline']['frac']:.3f}")
+    assert max(timed, after) >= 0.55, (timed, after)
+
+
 @pytest.mark.parametrize("config,launcher", [(4, "driver"), (2, "self"), (4, "self")])
 def test_bench_two_ranks_gloo_on_one_device(config, launcher):
     """The N>1 flow of bench.py (sharding of segments / frames over ranks, all-gather of the payloads, vote on every

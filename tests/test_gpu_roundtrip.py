@@ -80,6 +80,22 @@ def determined_blocks(dec_oracle, coder_idx, shape):
     return ok.reshape(-1)[: h8 * w8]
 
 
+def marking_defined(enc_o, coder_idx, img, wm):
+    """Pixel mask of the blocks whose MARKING is defined to float32 accuracy (the same rules as tests/test_gpu_parity.py
+    and tests/test_gpu_svd.py): Dct -- |C21| > 1e-3, else np.sign(C21) is decided by the last bits of the colour
+    transform (15 % of this JPEG-decoded frame's blocks are chroma-flat); DwtDctSvd -- s0 not within 1e-3 of a multiple
+    of the step and s1/s0 < 1 - 1e-3."""
+    enc_o.read_wm(wm)
+    enc_o.encode(orc.bgr2yuv_f32(img.astype(np.float32)))
+    if coder_idx == 3:
+        ok = np.abs(enc_o.debug["c21_pre"]) > 1e-3
+    else:
+        s0, gap = enc_o.debug["s0"].astype(np.float64), enc_o.debug["gap"]
+        frac = np.mod(s0, 15.0)
+        ok = (np.minimum(frac, 15.0 - frac) > 1e-3 * np.maximum(1.0, s0 / 100)) & (gap < 1 - 1e-3)
+    return np.kron(ok, np.ones((8, 8), bool))
+
+
 @pytest.mark.parametrize("gen_idx,coder_idx", [(0, 0), (0, 3), (1, 0), (1, 3)])
 def test_reference_round_trip_harness_with_jpeg(gen_idx, coder_idx):
     from offmark.video.color import bgr2yuv, yuv2bgr
@@ -96,8 +112,9 @@ def test_reference_round_trip_harness_with_jpeg(gen_idx, coder_idx):
     # the batch path of the same classes (u8 in, u8 out: what Embedder uses) marks the same pixels
     import torch
     fast = encoder.encode_frames_u8(torch.from_numpy(img[None]).cuda())[0].cpu().numpy()
-    d = np.abs(fast.astype(int) - wmed.astype(int))
-    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())     # float32 YUV frame in memory vs fused registers
+    defined = marking_defined(enc_o, coder_idx, img, wm)
+    d = np.abs(fast.astype(int) - wmed.astype(int))[defined]
+    assert defined.mean() > 0.8 and d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())   # float32 YUV frame in memory vs fused registers
     # -- :99,111  cv2.imwrite / cv2.imread
     rx = jpeg_round_trip(wmed)
     assert rx.shape == img.shape and (rx != wmed).mean() > 0.05                 # a lossy leg, not a no-op

@@ -156,11 +156,17 @@ def test_mark_py_and_detect_py_logic_literally(eng):
     assert np.abs(got[:, :, 1] - ref[:, :, 1])[blk_ok].max() <= 2e-3
     bits = DwtDctSvdDecoder().decode(ref)
     ref_bits = orc.DwtDctSvdDecoderOracle().decode(ref)
-    assert bits.dtype == np.float64 and bits.shape == ref_bits.shape and (bits != ref_bits).sum() <= 6
+    assert bits.dtype == np.float64 and bits.shape == ref_bits.shape
+    # raw bits at the float32 plugin boundary: the file's budget (1e-4 of the blocks, floor 1) over determined blocks --
+    # the others (s0 within 1e-3 of a multiple of the step, or s1 ~ s0: the marking itself is not defined to float32
+    # accuracy there) are masked as in the u8 tests
+    assert (bits != ref_bits).reshape(-1)[ok.reshape(-1)].sum() <= budget(int(ok.sum()), 1e-4)
     with pytest.raises(NotImplementedError):
         DwtDctSvdEncoder(blk=8)
     with pytest.raises(ValueError):
         DwtDctSvdEncoder(scales=[0, 0, 0])
+    with pytest.raises(ValueError):
+        DwtDctSvdEncoder(scales=[0, 1e-46, 0])          # a positive scale that float32 flushes to zero marks nothing
     # per-channel scales at the plugin boundary (dwt_dct_svd_encoder.py:19-26): every marked channel changes
     sc = [10, 15, 20]
     enc3 = DwtDctSvdEncoder(scales=sc)
@@ -175,7 +181,7 @@ def test_mark_py_and_detect_py_logic_literally(eng):
         assert np.abs(got3[:, :, ch] - want[:, :, ch])[blk3].max() <= 3e-3, ch
         assert not np.array_equal(got3[:, :, ch], yuv[:, :, ch])
     bits3 = DwtDctSvdDecoder(scales=sc).decode(want)
-    assert (bits3 != orc.DwtDctSvdDecoderOracle(scales=sc).decode(want)).sum() <= 6
+    assert (bits3 != orc.DwtDctSvdDecoderOracle(scales=sc).decode(want)).reshape(-1)[ok3.reshape(-1)].sum() <= budget(int(ok3.sum()), 1e-4)
     assert not DwtDctSvdDecoder(scales=[12, 0, 0]).decode(want).any()
 
 

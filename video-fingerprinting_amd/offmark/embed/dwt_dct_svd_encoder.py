@@ -18,6 +18,10 @@ def _check_scales(scales, blk, need_a_mark=True):
     if blk != 4:
         raise NotImplementedError("the HIP DwtDctSvd codec implements blk=4 (the reference's default, the only value "
                                   "for which its capacity and its block loop agree); got blk=%r" % (blk,))
+    for x in scales:
+        # the same rule as the C ABI (offmark_kernels.hip: set_scales): decided on the float32 value the kernels use
+        if not np.isfinite(x) or (x > 0 and not np.float32(x) >= np.float32(1e-3)):
+            raise ValueError("scales must be finite, and a positive scale at least 1e-3 as float32; got %r" % (scales,))
     if need_a_mark and not any(x > 0 for x in scales):
         raise ValueError("no channel has a positive scale: nothing would be marked")
     return scales
