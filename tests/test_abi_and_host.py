@@ -257,3 +257,81 @@ def test_header_is_plain_c_and_the_c_host_example_links(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     build_abi_demo(str(tmp_path / "abi_demo"))
+
+
+def test_pipeline_host_side_read_ahead_and_writer_protocol():
+    """Host logic of offmark/video/pipeline.py that needs no GPU: the read-ahead thread over every kind of reader
+    (batches, read_batch_into, bare read()), order and ragged tail, error hand-over, size check, threaded host copy,
+    the frame-shape rules of the pix_fmt route, PeekedReader, and ArrayFrameWriter's plain (copying) form."""
+    import queue
+    from offmark.video import pipeline as pl
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark.video.frame_writer import ArrayFrameWriter
+    frames = np.arange(11 * 4 * 6 * 3, dtype=np.uint8).reshape(11, 4, 6, 3)
+
+    class Bare:
+        def __init__(self, fr, fail_at=None):
+            self.fr, self.i, self.fail_at = list(fr), 0, fail_at
+
+        def read(self):
+            if self.i == self.fail_at:
+                raise IOError("boom")
+            self.i += 1
+            return self.fr[self.i - 1] if self.i <= len(self.fr) else None
+
+        def close(self):
+            pass
+
+    class Into(Bare):
+        def read_batch_into(self, buf):
+            n = 0
+            while n < len(buf):
+                f = self.read()
+                if f is None:
+                    break
+                buf[n] = f
+                n += 1
+            return n
+
+    def drain(reader, batch=4, staging=3):
+        ra = pl._ReadAhead(reader, batch, (4, 6, 3), np.uint8, [np.empty((batch, 4, 6, 3), np.uint8) for _ in range(staging)])
+        ra.start()
+        got = []
+        while True:
+            item = ra.ready.get(timeout=30)
+            if item is None or isinstance(item, BaseException):
+                ra.shutdown()
+                return got, item
+            view, st = item
+            got.append(view.copy())
+            if st is not None:
+                ra.free.put(st)
+
+    for reader in (ArrayFrameReader(frames), Bare(frames), Into(frames)):
+        got, end = drain(reader)
+        assert end is None and [len(g) for g in got] == [4, 4, 3] and np.array_equal(np.concatenate(got), frames)
+    got, end = drain(Bare(frames, fail_at=6))
+    assert isinstance(end, IOError) and np.array_equal(np.concatenate(got), frames[:4])       # the complete batch came through first
+    got, end = drain(Bare(list(frames[:5]) + [np.zeros((5, 6, 3), np.uint8)]))
+    assert isinstance(end, ValueError) and "expected" in str(end)
+    got, end = drain(Bare([]))
+    assert got == [] and end is None
+    big = np.random.default_rng(0).integers(0, 256, (40, 512, 512, 3), dtype=np.uint8)        # 31 MB: the threaded path
+    dst = np.empty_like(big)
+    pl.host_copy(dst, big)
+    assert np.array_equal(dst, big)
+    assert pl.frame_shape("rgb24", 240, 320) == (240, 320, 3) and pl.frame_shape("yuv420p", 240, 320) == (360, 320)
+    with pytest.raises(ValueError):
+        pl.frame_shape("nv12", 241, 320)
+    with pytest.raises(ValueError):
+        pl.pix_fmt_of(type("R", (), {"pix_fmt": "yuv444p"})())
+    assert pl.pix_fmt_of(object()) == "rgb24"
+    pk = pl.PeekedReader(Bare(frames[:3]))
+    assert (pk.height, pk.width) == (4, 6) and np.array_equal(np.stack([pk.read(), pk.read(), pk.read()]), frames[:3]) and pk.read() is None
+    w = ArrayFrameWriter()
+    assert w.reserve(4) is None                                  # no page-locked block: the pipeline falls back to write_batch
+    buf = frames[:4].copy()
+    w.write_batch(buf)
+    buf[:] = 0                                                   # the caller reuses its buffer: the writer kept a copy
+    assert np.array_equal(np.stack(w.frames), frames[:4])
+    assert queue.Queue                                           # (imported for the timeout above)

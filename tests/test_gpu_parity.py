@@ -1002,6 +1002,10 @@ def test_bench_configs_run_at_one_gpu(config, extra):
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"]
     assert line["hbm_copy_GBps"] > 1000 and line["hbm_read_GBps"] > 1000      # sanity only: a rate, not a ranking
+    if config == 5:        # BASELINE configs[4]: the attack suite is reported next to the line; clean and noisy leaks must resolve
+        atk = line["attacks"]
+        assert atk["none"]["copies_recovered"] and atk["none"]["payload_ber"] == 0 and atk["noise_sigma2"]["copies_recovered"]
+        assert all(k in atk for k in ("scale_2_3_and_back", "crop16_and_resize_back", "jpeg_q95_420", "jpeg_q75_420"))
     if config == 2:
         assert line["value_separate_detect"] > 0 and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["planar_i420"]["value"] > 0
