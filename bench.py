@@ -183,8 +183,9 @@ def attack_suite(torch, eng, clean, per_seg, payloads, chosen, fp, vote_segments
     """BASELINE.json configs[4]: the leak's frames under the build-defined attacks of SURVEY 8d (none exist upstream: the
     reference's only lossy leg is a JPEG, tests/test.py:99, and its HLS re-encode).  `clean`: marked frames [S * per_seg, H, W, 3]
     on the device.  Per attack: payload bit error rate over the frames, frames decoded exactly, segments whose Counter vote is
-    right, and whether the leak's copy sequence comes out.  Reported honestly: scaling and cropping move the 8x8 grid and are
-    EXPECTED to defeat a block-DCT QIM scheme; only "none" and "noise" are parity-gated (tests)."""
+    right, and whether the leak's copy sequence comes out.  Reported as measured: cropping moves the 8x8 grid and is EXPECTED to
+    defeat a block-DCT QIM scheme (so is a strong re-quantisation such as JPEG quality 75); a mild rescale may or may not survive
+    depending on the content; only "none" and "noise" are parity-gated (tests)."""
     import io
     S = len(payloads)
     seg = np.repeat(np.arange(S), per_seg)
@@ -229,7 +230,7 @@ def attack_suite(torch, eng, clean, per_seg, payloads, chosen, fp, vote_segments
         except Exception as exc:                                   # never lose the line over a side report
             out[name] = dict(error=repr(exc))
     out["note"] = (f"{per_seg} frames per segment, DCT codec; attacks are build-defined tensor ops between embed and detect (Pillow for the JPEGs); "
-                   "scale / crop break the 8x8 grid alignment and are expected to fail for this scheme")
+                   "a crop moves the 8x8 grid and is expected to fail for this scheme; the others are reported as measured")
     return out
 
 
