@@ -558,6 +558,21 @@ def main():
                                   payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
                                   algorithmic_GBps=round(n * k4 * 6 * H * W / el4 / 1e9, 1),
                                   note="DwtDctSvd embed + verify + payloads in one 6 B/px pass (scale 15)")
+        # the same codec with blk=8 (16x16 pixel tiles, an 8x8 singular-triplet solve per tile; H*W/256 bits per frame)
+        def svd8_step():
+            _, c, _ = e0.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, wm_row=rows_dev, out=out, blk=8)
+            return e0.payloads(c, H * W // 256, perm_dev)
+        svd8_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k4):
+            pm = svd8_step()
+        fence()
+        el5 = time.perf_counter() - t0
+        extra["dwtdctsvd_blk8"] = dict(value=round(world * n * k4 / el5, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el5 / k4, 4),
+                                       payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
+                                       algorithmic_GBps=round(n * k4 * 6 * H * W / el5 / 1e9, 1),
+                                       note="DwtDctSvd(blk=8) embed + verify + payloads (not tuned: the tile is read twice)")
 
     if rank != 0:
         if world > 1:

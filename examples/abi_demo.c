@@ -105,12 +105,12 @@ int main(void) {
 
     /* DwtDctSvd codec (what tests/mark.py constructs), scales = [0, 15, 0] */
     const double scales[3] = {0.0, 15.0, 0.0};
-    CHECK_OFMK(ofmk_svd_embed_detect_rgb8(d_in, d_out, N_FRAMES, H, W, d_wm, 1, NULL, scales, L, d_counts, NULL, stream, NULL));
+    CHECK_OFMK(ofmk_svd_embed_detect_rgb8(d_in, d_out, N_FRAMES, H, W, d_wm, 1, NULL, scales, 4, L, d_counts, NULL, stream, NULL));
     CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream, NULL));
     CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     ok &= payloads_ok(h_payload, "DwtDctSvd ofmk_svd_embed_detect_rgb8");
-    CHECK_OFMK(ofmk_svd_detect_rgb8(d_out, N_FRAMES, H, W, L, scales, d_counts, NULL, stream, NULL));
+    CHECK_OFMK(ofmk_svd_detect_rgb8(d_out, N_FRAMES, H, W, L, scales, 4, d_counts, NULL, stream, NULL));
     CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, n_bits, d_perm, d_payload, stream, NULL));
     CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));

@@ -121,21 +121,25 @@ int ofmk_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
  *            detection with scales[1] <= 0 yields zeros, as in the reference.  A positive scale must be a normal
  *            float32 >= 1e-3 after conversion (smaller steps are below the float32 resolution of typical top
  *            singular values; rejected with OFMK_E_ARG), NaN / infinities are rejected.
+ *   blk      DwtDctSvdEncoder(blk=4): the LL block size, 4 (the reference's default: 8x8 pixel tiles, one bit per tile,
+ *            N = H*W/64 bits) or 8 (16x16 pixel tiles: tile c takes wm[c], so the first quarter of the watermark row is
+ *            used, dwt_dct_svd_encoder.py:29-40, and `bits` is [n][H*W/256], dwt_dct_svd_decoder.py:14).  Other values:
+ *            OFMK_E_ARG (blk < 4 indexes past the reference's own watermark; larger blocks are not built).
  * Same frame/watermark/counts/bits conventions as the DCT entry points; no workspace (this codec has no
  * frame-global dependency: one pass).                                                            */
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
-                        const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, void *stream,
+                        const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, int blk, void *stream,
                         const ofmk_opts *opts);
-int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales,
+int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales, int blk,
                          int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
-                               const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales,
+                               const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, int blk,
                                int L, int32_t *counts, uint8_t *bits, void *stream, const ofmk_opts *opts);
 /* plugin level, float32 YUV [n][H][W][3] (n <= 65535): encode mutates the marked channels; decode fills bits */
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W,
-                           const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, void *stream,
+                           const uint8_t *wm, int n_wm, const int32_t *wm_row, const double *scales, int blk, void *stream,
                            const ofmk_opts *opts);
-int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream,
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, int blk, uint8_t *bits, void *stream,
                            const ofmk_opts *opts);
 
 /* ---- planar 8-bit YUV 4:2:0 on either side of the DCT codec ------------------------------

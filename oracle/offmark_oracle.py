@@ -616,9 +616,18 @@ class DctDecoderOracle:
 # (f)-1  DwtDctSvd codec (embed/dwt_dct_svd_encoder.py:5-45, extract/dwt_dct_svd_decoder.py:5-37)
 # --------------------------------------------------------------------------------------
 
-def to_blocks4(plane: np.ndarray) -> np.ndarray:
-    h4, w4 = plane.shape[0] // 4, plane.shape[1] // 4
-    return np.ascontiguousarray(plane[: h4 * 4, : w4 * 4].reshape(h4, 4, w4, 4).transpose(0, 2, 1, 3))
+def to_blocks4(plane: np.ndarray, blk: int = 4) -> np.ndarray:
+    hb, wb = plane.shape[0] // blk, plane.shape[1] // blk
+    return np.ascontiguousarray(plane[: hb * blk, : wb * blk].reshape(hb, blk, wb, blk).transpose(0, 2, 1, 3))
+
+
+def _svd_dct(blocks: np.ndarray, blk: int, inverse: bool = False) -> np.ndarray:
+    """``cv2.dct`` / ``cv2.idct`` on blk x blk float32 blocks (dwt_dct_svd_encoder.py:43-45): blk = 4 (default) or 8."""
+    if blk == 4:
+        return idct4x4(blocks) if inverse else dct4x4(blocks)
+    if blk == 8:
+        return idct8x8(blocks) if inverse else dct8x8(blocks)
+    raise NotImplementedError("the DwtDctSvd oracle restates cv2.dct for blk = 4 and blk = 8; got %r" % (blk,))
 
 
 class DwtDctSvdEncoderOracle:
@@ -651,19 +660,21 @@ class DwtDctSvdEncoderOracle:
                 c = 0
                 for i in range(rows):
                     for j in range(cols):
-                        blk = ca[i * 4:i * 4 + 4, j * 4:j * 4 + 4]
-                        u, s, v = np.linalg.svd(dct4x4(blk))
+                        n = self.blk
+                        blk = ca[i * n:i * n + n, j * n:j * n + n]
+                        u, s, v = np.linalg.svd(_svd_dct(blk, n))
                         s[0] = (s[0] // scale + 0.25 + 0.5 * self.wm[c]) * scale
-                        ca[i * 4:i * 4 + 4, j * 4:j * 4 + 4] = idct4x4(np.dot(u, np.dot(np.diag(s), v)))
+                        ca[i * n:i * n + n, j * n:j * n + n] = _svd_dct(np.dot(u, np.dot(np.diag(s), v)), n, inverse=True)
                         c += 1
             else:
-                blocks = to_blocks4(ca)
-                u, s, v = np.linalg.svd(dct4x4(blocks))
+                n = self.blk
+                blocks = to_blocks4(ca, n)
+                u, s, v = np.linalg.svd(_svd_dct(blocks, n))
                 s0 = s[..., 0].copy()
                 bits = np.asarray(self.wm)[: rows * cols].reshape(rows, cols)
                 s[..., 0] = ((s[..., 0] // scale + 0.25 + 0.5 * bits) * scale).astype(F32)
-                new = idct4x4(np.matmul(u, s[..., :, None] * v))
-                ca[: rows * 4, : cols * 4] = new.transpose(0, 2, 1, 3).reshape(rows * 4, cols * 4)
+                new = _svd_dct(np.matmul(u, s[..., :, None] * v), n, inverse=True)
+                ca[: rows * n, : cols * n] = new.transpose(0, 2, 1, 3).reshape(rows * n, cols * n)
                 self.debug_ch[channel] = dict(s0=s0, s0_new=s[..., 0].copy(), gap=(s[..., 1] / np.maximum(s0, 1e-30)))
                 self.debug = self.debug_ch[channel] if channel == 1 or 1 not in self.debug_ch else self.debug_ch[1]
             yuv[: row // 4 * 4, : col // 4 * 4, channel] = haar_idwt2((ca, hvd))
@@ -689,11 +700,12 @@ class DwtDctSvdDecoderOracle:
                 c = 0
                 for i in range(rows):
                     for j in range(cols):
-                        _, s, _ = np.linalg.svd(dct4x4(ca[i * 4:i * 4 + 4, j * 4:j * 4 + 4]))
+                        n = self.blk
+                        _, s, _ = np.linalg.svd(_svd_dct(ca[i * n:i * n + n, j * n:j * n + n], n))
                         wm_bits[channel][c] = int((s[0] % scale) > scale * 0.5)
                         c += 1
             else:
-                s = np.linalg.svd(dct4x4(to_blocks4(ca)), compute_uv=False)
+                s = np.linalg.svd(_svd_dct(to_blocks4(ca, self.blk), self.blk), compute_uv=False)
                 wm_bits[channel][: rows * cols] = ((s[..., 0] % scale) > scale * 0.5).reshape(-1)
                 self.debug = dict(s0=s[..., 0])
         return np.array(wm_bits[1]).reshape(1, -1)

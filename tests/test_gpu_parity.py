@@ -684,8 +684,9 @@ def test_long_and_oversized_payloads_and_empty_inputs(eng):
     wm = cuda(orc.shuffle_generate(P8, (1, N), 0).astype(np.uint8))
     s = _hip.current_stream()
     assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 0, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(), ws.numel(), s, None) == -1
-    assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, _hip.scales3(0), s, None) == -1
-    assert lib.ofmk_svd_detect_rgb8(f.data_ptr(), 1, H, W, 8, _hip.scales3(15), None, None, s, None) == -1
+    assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, _hip.scales3(0), 4, s, None) == -1
+    assert lib.ofmk_svd_detect_rgb8(f.data_ptr(), 1, H, W, 8, _hip.scales3(15), 4, None, None, s, None) == -1
+    assert lib.ofmk_svd_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, _hip.scales3(15), 5, s, None) == -1       # blk: 4 or 8
     assert lib.ofmk_payloads_from_counts(None, 1, 8, N, None, None, s, None) == -1
     unaligned = torch.empty(ws.numel() + 1, dtype=torch.uint8, device="cuda")[1:]
     assert lib.ofmk_embed_rgb8(f.data_ptr(), f.data_ptr(), 1, H, W, wm.data_ptr(), 1, None, 20.0, 0, unaligned.data_ptr(), ws.numel(), s, None) == -1
@@ -1010,6 +1011,7 @@ def test_bench_configs_run_at_one_gpu(config, extra):
         assert line["value_separate_detect"] > 0 and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["planar_i420"]["value"] > 0
         assert line["dwtdctsvd"]["payload_ok"] and line["dwtdctsvd"]["value"] > 0
+        assert line["dwtdctsvd_blk8"]["payload_ok"] and line["dwtdctsvd_blk8"]["value"] > 0
         assert "device_under_load" in line                     # a sample or an error text, never a crash of the line
         # both rates are reported, not ranked: the PCIe leg shares the host with whatever else runs on the box
         assert line["pcie_inclusive"]["i420"]["frames_per_s"] > 0 and line["pcie_inclusive"]["rgb24"]["frames_per_s"] > 0

@@ -41,9 +41,9 @@ def budget(n, frac, floor=1):
     return max(floor, int(np.floor(n * frac)))
 
 
-def determined_pixels(frame, wm, scales=(0, 15, 0)):
+def determined_pixels(frame, wm, scales=(0, 15, 0), blk=4):
     """Blocks whose marking is defined to float32 accuracy in EVERY marked channel (see the module text)."""
-    enc = orc.DwtDctSvdEncoderOracle(scales=scales)
+    enc = orc.DwtDctSvdEncoderOracle(scales=scales, blk=blk)
     enc.read_wm(wm)
     enc.encode(orc.bgr2yuv_f32(frame.astype(np.float32)))
     ok = None
@@ -55,7 +55,8 @@ def determined_pixels(frame, wm, scales=(0, 15, 0)):
         ok = this if ok is None else ok & this
     H, W, _ = frame.shape
     m = np.ones((H, W), bool)
-    m[: ok.shape[0] * 8, : ok.shape[1] * 8] = np.kron(ok, np.ones((8, 8), bool))
+    px = 2 * blk                                     # pixels per tile side
+    m[: ok.shape[0] * px, : ok.shape[1] * px] = np.kron(ok, np.ones((px, px), bool))
     return m, ok
 
 
@@ -72,18 +73,22 @@ def test_svd_golden_embed_and_detect(eng, case):
     g = np.load(os.path.join(GOLDEN, case + ".npz"))
     frame = g["frame"]
     H, W, _ = frame.shape
-    N, nblk = H * W // 64, (H // 8) * (W // 8)
     scales = tuple(float(x) for x in g["scales"]) if "scales" in g.files else (0.0, 15.0, 0.0)      # round 2: per-channel scales
-    marked = eng.svd_embed(cuda(frame[None]), g["wm"], scales=scales)[0].cpu().numpy()
-    mask, ok = determined_pixels(frame, g["wm"], scales)
-    assert ok.mean() > (0.9 if sum(x > 0 for x in scales) == 1 else 0.8)
+    blk = int(g["blk"]) if "blk" in g.files else 4                                                  # round 3: blk = 8
+    px = 2 * blk
+    th, tw = (H // 4 * 2) // blk, (W // 4 * 2) // blk                 # tiles (dwt_dct_svd_encoder.py:29-32 on the LL band)
+    N, nblk = H * W // 4 // (blk * blk), th * tw                       # the decoder's bit count (decoder.py:14) and the tiles it fills
+    marked = eng.svd_embed(cuda(frame[None]), g["wm"], scales=scales, blk=blk)[0].cpu().numpy()
+    mask, ok = determined_pixels(frame, g["wm"], scales, blk)
+    if nblk >= 32:
+        assert ok.mean() > (0.9 if sum(x > 0 for x in scales) == 1 else 0.8)
     assert_pixels_close(marked, g["marked"], mask)
-    assert np.array_equal(marked[(H // 8) * 8:], frame[(H // 8) * 8:]) and np.array_equal(marked[:, (W // 8) * 8:], frame[:, (W // 8) * 8:])
+    assert np.array_equal(marked[th * px:], frame[th * px:]) and np.array_equal(marked[:, tw * px:], frame[:, tw * px:])
     if not (scales[0] > 0 or scales[2] > 0):
         assert np.array_equal(marked[..., 2], frame[..., 2])          # channel 2 untouched when only U is marked
-    counts, bits = eng.svd_detect(cuda(g["marked"][None]), 8, want_bits=True, scales=scales)
+    counts, bits = eng.svd_detect(cuda(g["marked"][None]), 8, want_bits=True, scales=scales, blk=blk)
     bits = bits[0].cpu().numpy()
-    assert bits.shape == (N,) and not bits[nblk:].any()
+    assert bits.shape == (N,) == g["raw_bits"].reshape(-1).shape and not bits[nblk:].any()
     assert (bits != g["raw_bits"].reshape(-1)).sum() <= budget(nblk, 1e-4)
     assert np.array_equal(counts[0].cpu().numpy(), np.array([bits[i::8].sum() for i in range(8)]))
     if scales[1] > 0:
@@ -92,10 +97,30 @@ def test_svd_golden_embed_and_detect(eng, case):
     else:                                            # the reference reads channel 1 only (decoder.py:24): zeros
         assert not bits.any() and not g["raw_bits"].any()
     # fused embed+verify == embed followed by detect
-    o2, c2, b2 = eng.svd_embed_detect(cuda(frame[None]), g["wm"], 8, want_bits=True, scales=scales)
-    c3, b3 = eng.svd_detect(o2, 8, want_bits=True, scales=scales)
+    o2, c2, b2 = eng.svd_embed_detect(cuda(frame[None]), g["wm"], 8, want_bits=True, scales=scales, blk=blk)
+    c3, b3 = eng.svd_detect(o2, 8, want_bits=True, scales=scales, blk=blk)
     import torch
     assert torch.equal(c2, c3) and torch.equal(b2, b3) and np.array_equal(o2[0].cpu().numpy(), marked)
+    # in place, and the plugin classes (DwtDctSvdEncoder(blk=...).encode / DwtDctSvdDecoder(blk=...).decode on float32 YUV)
+    buf = cuda(frame[None]).clone()
+    eng.svd_embed(buf, g["wm"], scales=scales, blk=blk, out=buf)
+    assert np.array_equal(buf[0].cpu().numpy(), marked)
+    if blk != 4 and "yuv_in" in g.files:
+        from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder
+        from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder
+        enc = DwtDctSvdEncoder(scales=list(scales), blk=blk)
+        enc.read_wm(g["wm"])
+        got = enc.encode(g["yuv_in"].copy())
+        tile_ok = np.kron(ok, np.ones((px, px), bool))
+        for ch in range(3):
+            d = np.abs(got[: th * px, : tw * px, ch] - g["yuv_out"][: th * px, : tw * px, ch])
+            assert d[tile_ok].max() <= 3e-3, ch
+            if not scales[ch] > 0:
+                assert np.array_equal(got[:, :, ch], g["yuv_in"][:, :, ch])
+        dec = DwtDctSvdDecoder(scales=list(scales), blk=blk)
+        rb = dec.decode(g["yuv_out"].copy())
+        assert rb.shape == (1, N) and dec.block_num == N
+        assert (rb != g["raw_bits_clean"]).reshape(-1)[: nblk][ok.reshape(-1)].sum() <= budget(nblk, 1e-4)
 
 
 def test_svd_1080p_against_oracle_and_payloads(eng):
@@ -115,6 +140,49 @@ def test_svd_1080p_against_oracle_and_payloads(eng):
     assert (b2[0].cpu().numpy() != ref_bits.reshape(-1)).sum() <= budget(32400, 1e-4)
     deg = DeShuffler(key=0).set_shape((8,))
     assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), 32400), P8)
+
+
+def test_svd_blk8_full_frames_against_oracle_and_payloads(eng):
+    """DwtDctSvd*(blk=8) at 1080p (67 x 120 tiles of 16x16 pixels, 4 LL rows of fringe) and on the reference's natural frame:
+    marked pixels against the oracle over determined tiles, the read-out of the oracle's marked frame, payloads, the
+    per-channel-scales form, several frames with own rows, and that nothing outside the tiles changes."""
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from conftest import natural_frame
+    H, W = 1080, 1920
+    N8, th, tw = H * W // 256, (H // 4 * 2) // 8, (W // 4 * 2) // 8
+    wm = orc.shuffle_generate(P8, (1, H * W // 64), 0)
+    deg = DeShuffler(key=0).set_shape((8,))
+    for frame, scales in ((orc.synthetic_frame(H, W, 2000), (0, 15, 0)), (natural_frame(), (0, 15, 0)), (orc.synthetic_frame(H, W, 2001), (9, 15, 21))):
+        enc = orc.DwtDctSvdEncoderOracle(scales=scales, blk=8)
+        enc.read_wm(wm)
+        ref = orc.mark_frame(frame, enc)
+        marked, counts, bits = eng.svd_embed_detect(cuda(frame[None]), wm, 8, want_bits=True, scales=scales, blk=8)
+        mask, ok = determined_pixels(frame, wm, scales, blk=8)
+        assert ok.shape == (th, tw) and ok.mean() > 0.8
+        m = marked[0].cpu().numpy()
+        assert_pixels_close(m, ref, mask)
+        assert np.array_equal(m[th * 16:], frame[th * 16:]) and np.array_equal(m[:, tw * 16:], frame[:, tw * 16:])
+        ref_bits = orc.check_frame(ref, orc.DwtDctSvdDecoderOracle(scales=scales, blk=8)).reshape(-1)
+        assert ref_bits.shape == (N8,)
+        _, b2 = eng.svd_detect(cuda(ref[None]), 8, want_bits=True, scales=scales, blk=8)
+        assert (b2[0].cpu().numpy() != ref_bits).sum() <= budget(th * tw, 1e-4)
+        assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), N8), P8)
+    # a batch with per-frame rows (the clamp included) equals frame-by-frame calls
+    frames = cuda(np.stack([orc.synthetic_frame(240, 320, 1001 + i) for i in range(5)]))
+    table = np.stack([orc.shuffle_generate(np.roll(P8, i), (1, 1200), 0)[0] for i in range(3)]).astype(np.uint8)
+    rows = [2, 0, 1, 1, 2]
+    batch = eng.svd_embed(frames, table, wm_row=rows, blk=8)
+    for i, r in enumerate(rows):
+        assert torch.equal(batch[i], eng.svd_embed(frames[i:i + 1], table[r:r + 1], blk=8)[0])
+    c, _ = eng.svd_detect(batch, 8, blk=8)
+    got = deg.degenerate_counts(c.cpu().numpy(), 240 * 320 // 256)
+    assert all(np.array_equal(got[i], np.roll(P8, rows[i])) for i in range(5))
+    # frames smaller than one tile: nothing to mark, nothing to read
+    tiny = cuda(orc.synthetic_frame(12, 40, 3)[None])
+    assert torch.equal(eng.svd_embed(tiny, np.zeros((1, 7), np.uint8), blk=8), tiny)
+    c0, b0 = eng.svd_detect(tiny, 8, want_bits=True, blk=8)
+    assert not c0.any() and b0.shape == (1, 12 * 40 // 256) and not b0.any()
 
 
 def test_mark_py_and_detect_py_logic_literally(eng):
@@ -162,7 +230,8 @@ def test_mark_py_and_detect_py_logic_literally(eng):
     # accuracy there) are masked as in the u8 tests
     assert (bits != ref_bits).reshape(-1)[ok.reshape(-1)].sum() <= budget(int(ok.sum()), 1e-4)
     with pytest.raises(NotImplementedError):
-        DwtDctSvdEncoder(blk=8)
+        DwtDctSvdEncoder(blk=2)                          # indexes past the reference's own watermark; not built
+    assert DwtDctSvdEncoder(blk=8).blk == 8              # round 3: 16x16 pixel tiles (golden cases svd_blk8_*)
     with pytest.raises(ValueError):
         DwtDctSvdEncoder(scales=[0, 0, 0])
     with pytest.raises(ValueError):

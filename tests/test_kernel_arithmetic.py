@@ -229,6 +229,191 @@ def test_svd_top_value_solver_float32_replay():
     assert rel[big].max() <= 1e-4 and rel[big].max() * 2040 < 0.25 * min_loose, rel[big].max()
 
 
+# ---- DwtDctSvd with blk = 8: top singular triplet of an 8x8 block (svd8_kernels.hiph) -------------------------------------
+def _svd8_gram(B):
+    n=8; G=np.zeros(B.shape[:1]+(n,n),F)
+    for i in range(n):
+        for j in range(i,n):
+            acc=B[:,0,i]*B[:,0,j]
+            for k in range(1,n): acc=fma(B[:,k,i],B[:,k,j],acc)
+            G[:,i,j]=acc; G[:,j,i]=acc
+    return G
+
+def _svd8_solve(B, tol=F(2e-7), cap=16, want_vec=True):
+    """svd8_top() of csrc/svd8_kernels.hiph step by step in float32 (fma = exact product, one rounding; the kernel's
+    Newton-refined reciprocals are exact divisions here): Gram matrix, trace scaling, six Householder reflections,
+    Laguerre from above on the degree-8 characteristic polynomial, twisted factorisation for the eigenvector,
+    back-transformation, w = B v, s0 = |w|."""
+    n=8; N=B.shape[0]
+    G=_svd8_gram(B)
+    tr=G[:,0,0].copy()
+    for i in range(1,n): tr=tr+G[:,i,i]
+    with np.errstate(all='ignore'):
+        inv=np.where(tr>0, F(1)/tr, F(0)).astype(F)
+    A=(G*inv[:,None,None]).astype(F)
+    a=np.zeros((N,n),F); b=np.zeros((N,n-1),F)
+    V=[]; BETA=[]
+    for k in range(n-2):
+        m=n-1-k
+        x=[A[:,k,k+1+i].copy() for i in range(m)]
+        tail=x[1]*x[1]
+        for i in range(2,m): tail=fma(x[i],x[i],tail)
+        n2=fma(x[0],x[0],tail)
+        nrm=np.sqrt(n2)
+        v0=x[0]+np.copysign(nrm,x[0])
+        vtv=fma(v0,v0,tail)
+        with np.errstate(all='ignore'):
+            beta=np.where(tail>F(1e-30), F(2)/vtv, F(0)).astype(F)
+        v=[v0]+x[1:]
+        # trailing submatrix S (m x m) = A[k+1.., k+1..]
+        p=[]
+        for i in range(m):
+            acc=A[:,k+1+i,k+1]*v[0]
+            for j in range(1,m): acc=fma(A[:,k+1+i,k+1+j],v[j],acc)
+            p.append(beta*acc)
+        K=v[0]*p[0]
+        for j in range(1,m): K=fma(v[j],p[j],K)
+        K=F(0.5)*beta*K
+        q=[fma(-K,v[i],p[i]) for i in range(m)]
+        for i in range(m):
+            for j in range(i,m):
+                val=fma(-q[i],v[j],fma(-v[i],q[j],A[:,k+1+i,k+1+j]))
+                A[:,k+1+i,k+1+j]=val; A[:,k+1+j,k+1+i]=val
+        a[:,k]=A[:,k,k]
+        b[:,k]=np.where(tail>F(1e-30), -np.copysign(nrm,x[0]), x[0])
+        V.append(v); BETA.append(beta)
+    a[:,n-2]=A[:,n-2,n-2]; a[:,n-1]=A[:,n-1,n-1]; b[:,n-2]=A[:,n-2,n-1]
+    bq=(b*b).astype(F); nb=np.abs(b)
+    # Gershgorin / trace (=1 after scaling) start
+    g=a[:,0]+nb[:,0]
+    for i in range(1,n-1): g=np.maximum(g,a[:,i]+nb[:,i-1]+nb[:,i])
+    g=np.maximum(g,a[:,n-1]+nb[:,n-2])
+    lam=np.minimum(g,F(1)).astype(F)
+    active=np.ones(N,bool); iters=np.zeros(N,int)
+    for _ in range(cap):
+        d=[a[:,i]-lam for i in range(n)]
+        pm2,em2,fm2=np.ones(N,F),np.zeros(N,F),np.zeros(N,F)     # p0
+        pm1,em1,fm1=d[0],-np.ones(N,F),np.zeros(N,F)              # p1
+        for k in range(1,n):
+            pk=fma(d[k],pm1,-bq[:,k-1]*pm2)
+            ek=fma(d[k],em1,fma(-bq[:,k-1],em2,-pm1))
+            fk=fma(d[k],fm1,fma(-bq[:,k-1],fm2,F(-2)*em1))
+            pm2,em2,fm2,pm1,em1,fm1=pm1,em1,fm1,pk,ek,fk
+        with np.errstate(all='ignore'):
+            rp=(F(1)/pm1).astype(F)
+            gg=em1*rp
+            h=fma(gg,gg,-fm1*rp)
+            t=np.maximum(F(n-1)*fma(F(n),h,-gg*gg),F(0))
+            step=(F(n)/(gg+np.copysign(np.sqrt(t),gg))).astype(F)
+            step=np.where((pm1!=0)&(np.abs(step)<F(3e38)),step,F(0)).astype(F)
+        lam=np.where(active,lam-step,lam).astype(F)
+        iters+=active
+        active&=np.abs(step)>tol*np.abs(lam)
+        if not active.any(): break
+    lam=np.maximum(lam,F(0))
+    s0_val=np.sqrt(lam.astype(F)*tr).astype(F)
+    if not want_vec: return s0_val,None,iters
+    # twisted factorisation
+    tiny=F(1e-12)
+    def safe(D): return np.where(np.abs(D)<tiny, np.copysign(tiny,D), D).astype(F)
+    d=[a[:,i]-lam for i in range(n)]
+    Dp=[None]*n; Lp=[None]*(n-1)
+    Dp[0]=d[0]
+    with np.errstate(all='ignore'):
+        for i in range(n-1):
+            Lp[i]=(b[:,i]/safe(Dp[i])).astype(F)
+            Dp[i+1]=fma(-Lp[i],b[:,i],d[i+1])
+        Dm=[None]*n; Um=[None]*(n-1)
+        Dm[n-1]=d[n-1]
+        for i in range(n-2,-1,-1):
+            Um[i]=(b[:,i]/safe(Dm[i+1])).astype(F)
+            Dm[i]=fma(-Um[i],b[:,i],d[i])
+    gam=np.stack([np.abs((Dp[k]+Dm[k])-d[k]) for k in range(n)],1)
+    gam=np.where(np.isfinite(gam),gam,F(np.inf))
+    ks=np.argmin(gam,1)
+    z=np.zeros((N,n),F)
+    # per k* branch (vectorised by masks)
+    for kstar in range(n):
+        msk=ks==kstar
+        if not msk.any(): continue
+        zz=np.zeros((msk.sum(),n),F); zz[:,kstar]=1
+        for i in range(kstar-1,-1,-1): zz[:,i]=-Lp[i][msk]*zz[:,i+1]
+        for i in range(kstar,n-1): zz[:,i+1]=-Um[i][msk]*zz[:,i]
+        z[msk]=zz
+    # back transform: v = H0 H1 ... H5 z
+    for k in range(n-3,-1,-1):
+        m=n-1-k; v=V[k]
+        dot=v[0]*z[:,k+1]
+        for j in range(1,m): dot=fma(v[j],z[:,k+1+j],dot)
+        c=BETA[k]*dot
+        for j in range(m): z[:,k+1+j]=fma(-c,v[j],z[:,k+1+j])
+    n2=z[:,0]*z[:,0]
+    for i in range(1,n): n2=fma(z[:,i],z[:,i],n2)
+    with np.errstate(all='ignore'):
+        inv=np.where((n2>0)&np.isfinite(n2), F(1)/np.sqrt(n2), F(0)).astype(F)
+    vv=(z*inv[:,None]).astype(F)
+    bad=~((n2>0)&np.isfinite(n2))
+    vv[bad]=0; vv[bad,0]=1
+    # w = B v
+    w=np.zeros((N,n),F)
+    for i in range(n):
+        acc=B[:,i,0]*vv[:,0]
+        for j in range(1,n): acc=fma(B[:,i,j],vv[:,j],acc)
+        w[:,i]=acc
+    s0=w[:,0]*w[:,0]
+    for i in range(1,n): s0=fma(w[:,i],w[:,i],s0)
+    s0=np.sqrt(s0).astype(F)
+    return s0_val,(s0,w,vv),iters
+
+
+
+def test_svd8_top_triplet_solver_float32_replay():
+    """DwtDctSvd*(blk=8) needs the top singular triplet of 8x8 LL blocks (dwt_dct_svd_encoder.py:41-45 with blk=8).  The
+    kernel's algorithm (svd8_kernels.hiph: svd8_top) replayed in float32 against float64 LAPACK: random, LL-like,
+    flat-plus-noise, exactly / nearly repeated top singular values, rank-1 and zero blocks, and the 8x8 LL blocks of Y, U
+    and V of the reference's own frame63.jpeg.  The constants are read from the kernel source."""
+    from conftest import natural_frame
+    src = open(os.path.join(PKG, "csrc", "svd8_kernels.hiph")).read()
+    assert "svd8_top<true>(B, kTolTight, 16)" in src and "svd8_top<false>(B, kTolTight, 16)" in src
+    assert "7.f * fmaf(8.f, h, -g * g)" in src and "8.f * __builtin_amdgcn_rcpf(g + copysignf" in src      # Laguerre with n = 8
+    tiny = float(re.search(r"kTiny = ([0-9.eE+-]+)f;", src).group(1))
+    assert tiny == 1e-12
+    tol = F(float(re.search(r"kTolTight = ([0-9.eE+-]+)f", open(os.path.join(PKG, "csrc", "svd_kernels.hiph")).read()).group(1)))
+    rng = np.random.default_rng(5)
+    sets = [rng.uniform(-200, 200, (3000, 8, 8)), rng.uniform(0, 510, (3000, 8, 8)), 1 + rng.normal(0, 1, (3000, 8, 8)),
+            np.ones((1, 8, 8)) * rng.uniform(0, 300, (2000, 1, 1)) + rng.normal(0, 0.3, (2000, 8, 8))]
+    adv = [np.zeros((8, 8)), np.ones((8, 8)), np.eye(8) * 7, np.diag([5., 5, 1, 0, 0, 0, 0, 0]), np.diag([3., 3, 3, 3, 3, 3, 3, 3.0000001]),
+           np.diag([100., 99.9999, 1e-3, 0, 0, 0, 0, 0]), np.outer(np.arange(1., 9), np.arange(8., 0, -1)), np.diag([0., 0, 0, 0, 0, 0, 0, 9]),
+           np.diag([1e-3, 0, 0, 0, 0, 0, 0, 0])]
+    for k in range(400):
+        q1, _ = np.linalg.qr(rng.normal(size=(8, 8)))
+        q2, _ = np.linalg.qr(rng.normal(size=(8, 8)))
+        s = np.sort(rng.uniform(0, 4000, 8))[::-1]
+        if k % 4 == 0:
+            s[1] = s[0]
+        elif k % 4 == 1:
+            s[1] = s[0] * (1 - 1e-5)
+        elif k % 4 == 2:
+            s[1:] = 0
+        adv.append(q1 @ np.diag(s) @ q2.T)
+    yuv = orc.bgr2yuv_f32(natural_frame()[::2, ::2].astype(F))                 # a quarter of the frame keeps the test short
+    nat = [orc.to_blocks4(np.array(orc.haar_dwt2(yuv[: yuv.shape[0] // 4 * 4, : yuv.shape[1] // 4 * 4, ch])[0]), 8).reshape(-1, 8, 8) for ch in range(3)]
+    B = np.concatenate(sets + [np.array(adv)] + nat).astype(F)
+    U, S, Vt = np.linalg.svd(B.astype(np.float64))
+    ref, gap = S[:, 0], S[:, 1] / np.maximum(S[:, 0], 1e-30)
+    sval, (s0, w, v), iters = _svd8_solve(B, tol=tol)
+    big = ref > 1e-3
+    rel = lambda x: np.abs(x.astype(np.float64) - ref) / np.maximum(ref, 1e-30)      # noqa: E731
+    assert rel(sval)[big].max() <= 5e-7 and rel(s0)[big].max() <= 4e-7, (rel(sval)[big].max(), rel(s0)[big].max())   # measured 3.1e-7 / 2.5e-7
+    assert np.abs(sval - ref)[~big].max() <= 1e-3 and np.isfinite(v).all() and np.isfinite(s0).all()
+    assert iters.max() <= 16 and iters.mean() <= 3.0
+    # the rank-1 direction u0 v0^T the marking moves along: (w / s0) v^T against LAPACK's, where it is defined
+    R = (w[:, :, None] * v[:, None, :]) / np.maximum(s0, 1e-30)[:, None, None]
+    err = np.abs(R - U[:, :, 0][:, :, None] * Vt[:, 0, :][:, None, :]).reshape(len(B), -1).max(1)
+    assert err[big & (gap < 0.9)].max() <= 2e-6 and err[big & (gap < 0.99)].max() <= 2e-5          # measured 6e-7 / 5.2e-6
+    assert np.abs(np.linalg.norm(v.astype(np.float64), axis=1) - 1).max() <= 1e-6                   # unit vectors, the fallbacks included
+
+
 def test_fmod_shortcut_is_fmod():
     """fmod_pos (svd_kernels.hiph): trunc of an inflated quotient estimate, one fma, one fix-up == fmodf, bit for bit, for
     0 <= a < 2^20 * b.  Replayed in float32 with a 1-ulp-wrong reciprocal in both directions (v_rcp_f32 is accurate to 1 ulp)."""

@@ -77,12 +77,17 @@ def run_case(name, frame, payload, key, alpha, image_payload=False, store_yuv=Fa
           f"raw_ber={np.mean(raw_bits.reshape(-1)[:wm.size] != wm.reshape(-1)):.4f} payload_ok={ok}")
 
 
-def run_svd_case(name, frame, payload, key, store_yuv=False, scales=None):
+def run_svd_case(name, frame, payload, key, store_yuv=False, scales=None, blk=None):
     """mark.py / detect.py's codec pair (DwtDctSvdEncoder / DwtDctSvdDecoder) on one frame.
-    scales: per-channel quantisation steps (dwt_dct_svd_encoder.py:6,19-26); None = the reference's default [0,15,0]."""
+    scales: per-channel quantisation steps (dwt_dct_svd_encoder.py:6,19-26); None = the reference's default [0,15,0].
+    blk: LL block size (dwt_dct_svd_encoder.py:6,29-40); None = the reference's default 4."""
     h, w, _ = frame.shape
-    enc, dec = (DwtDctSvdEncoder(), DwtDctSvdDecoder()) if scales is None else \
-        (DwtDctSvdEncoder(scales=list(scales)), DwtDctSvdDecoder(scales=list(scales)))
+    kw = {}
+    if scales is not None:
+        kw["scales"] = list(scales)
+    if blk is not None:
+        kw["blk"] = int(blk)
+    enc, dec = DwtDctSvdEncoder(**kw), DwtDctSvdDecoder(**kw)
     wm = Shuffler(key=key).generate_wm(payload, enc.wm_capacity((h, w, 3)))
     enc.read_wm(wm)
     deg = DeShuffler(key=key).set_shape(payload.shape)
@@ -94,10 +99,13 @@ def run_svd_case(name, frame, payload, key, store_yuv=False, scales=None):
              raw_bits_clean=dec.decode(yuv_out.copy()), degenerated=deg.degenerate(raw_bits))
     if scales is not None:
         d["scales"] = np.asarray(scales, dtype=np.float64)
+    if blk is not None:
+        d["blk"] = np.int64(blk)
     if store_yuv:
         d.update(yuv_in=yuv_in, yuv_out=yuv_out)
     np.savez_compressed(os.path.join(OUT, "svd_" + name + ".npz"), **d)
-    print(f"svd_{name:24s} {h}x{w} raw_ber={np.mean(raw_bits.reshape(-1)[:wm.size] != wm.reshape(-1)):.4f} "
+    nb = min(raw_bits.size, wm.size)                       # blk=8: the decoder returns a quarter as many bits
+    print(f"svd_{name:24s} {h}x{w} raw_ber={np.mean(raw_bits.reshape(-1)[:nb] != wm.reshape(-1)[:nb]):.4f} "
           f"payload_ok={np.array_equal(d['degenerated'], payload)}")
 
 
@@ -111,6 +119,21 @@ def svd_scale_cases():
     run_svd_case("scales_0_9_25_syn_36x52", orc.synthetic_frame(36, 52, 6), P8, 7, store_yuv=True, scales=(0, 9, 25))
     run_svd_case("scales_0_0_30_syn_240x320", orc.synthetic_frame(240, 320, 1001), P8, 0, scales=(0, 0, 30))
     run_svd_case("scales_8_22_8_frame63_crop0", np.ascontiguousarray(nat[300:428, 600:728]), P8, 0, scales=(8, 22, 8))
+
+
+def svd_blk8_cases():
+    """Round 3: DwtDctSvd with blk=8 (16x16 pixel tiles; the encoder consumes the first quarter of the watermark, the decoder
+    returns row*col//256 bits: dwt_dct_svd_encoder.py:29-40, dwt_dct_svd_decoder.py:14)."""
+    from PIL import Image
+    P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    nat = np.asarray(Image.open("/root/reference/tests/media/imgs/frame63.jpeg").convert("RGB"))
+    run_svd_case("blk8_syn_64x96", orc.synthetic_frame(64, 96, 2), P8, 0, store_yuv=True, blk=8)
+    run_svd_case("blk8_syn_240x320", orc.synthetic_frame(240, 320, 1001), P8, 0, blk=8)
+    run_svd_case("blk8_syn_36x52", orc.synthetic_frame(36, 52, 6), P8, 7, store_yuv=True, blk=8)          # LL 18x26: 2x3 tiles, fringe untouched
+    run_svd_case("blk8_frame63_crop0", np.ascontiguousarray(nat[300:428, 600:728]), P8, 0, blk=8)
+    run_svd_case("blk8_scales_10_15_20_syn_64x96", orc.synthetic_frame(64, 96, 3), P8, 0, store_yuv=True, scales=(10, 15, 20), blk=8)
+    run_svd_case("blk8_edge_black_64x64", np.zeros((64, 64, 3), np.uint8), P8, 0, blk=8)
+    run_svd_case("blk8_edge_white_64x64", np.full((64, 64, 3), 255, np.uint8), P8, 0, blk=8)
 
 
 def grayscale_at_scale_digests():
@@ -150,6 +173,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--round2":       # add the round-2 fixtures without touching round 1's
         svd_scale_cases()
         grayscale_at_scale_digests()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--round3":
+        svd_blk8_cases()
         return
     P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
     run_svd_case("syn_64x96", orc.synthetic_frame(64, 96, 2), P8, 0, store_yuv=True)
@@ -220,6 +246,7 @@ def main():
 
     svd_scale_cases()
     grayscale_at_scale_digests()
+    svd_blk8_cases()
 
 
 if __name__ == "__main__":

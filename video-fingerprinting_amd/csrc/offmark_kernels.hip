@@ -39,6 +39,7 @@
 #include "common.hiph"
 #include "dct_kernels.hiph"
 #include "svd_kernels.hiph"
+#include "svd8_kernels.hiph"
 #include "misc_kernels.hiph"
 #include "planar_kernels.hiph"
 
@@ -254,7 +255,7 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
     }
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
+        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W, (H / 8) * 8, (W / 8) * 8);
         HIP_TRY(hipGetLastError());
     }
     return OFMK_OK;
@@ -351,10 +352,68 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
     }
     HIP_TRY(hipGetLastError());
     if (mode != SVD_DETECT && in != out && (H % 8 || W % 8)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W);
+        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W, (H / 8) * 8, (W / 8) * 8);
         HIP_TRY(hipGetLastError());
     }
     return OFMK_OK;
+}
+
+// blk = 8: 16x16 pixel tiles (svd8_kernels.hiph).  a.N = H*W/64 (watermark row stride), a.N8 = H*W/256 (bits per frame).
+Geom8 make_geom8(int H, int W) {
+    Geom8 g;
+    g.W = W;
+    g.wt = ((W / 4) * 2) / 8;
+    g.inv_wt = g.wt ? 1.0f / (float)g.wt : 0.f;
+    g.ntile = (((H / 4) * 2) / 8) * g.wt;
+    g.frame_stride = (size_t)H * W * 3;
+    return g;
+}
+
+int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mode, Svd8Args a, const Ctx &cx) {
+    hipStream_t s = cx.s;
+    const Geom8 g = make_geom8(H, W);
+    if (a.counts) HIP_TRY(hipMemsetAsync(a.counts, 0, (size_t)n * a.L * sizeof(int32_t), s));
+    if (a.bits && a.N8 > g.ntile) HIP_TRY(hipMemsetAsync(a.bits, 0, (size_t)n * a.N8, s));    // entries past the tiles stay 0
+    const int Hc = (((H / 4) * 2) / 8) * 16, Wc = g.wt * 16;                                    // the region the tiles cover
+    if (g.ntile > 0) {
+        const bool al = W % 8 == 0 && (uintptr_t)in % 8 == 0 && (mode == SVD_DETECT || (uintptr_t)out % 8 == 0);
+        for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
+            const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
+            const size_t fo = (size_t)f0 * g.frame_stride;
+            Svd8Args b = a;
+            if (b.wm_row) b.wm_row += f0;
+            if (b.counts) b.counts += (size_t)f0 * a.L;
+            if (b.bits) b.bits += (size_t)f0 * a.N8;
+            const dim3 grid((unsigned)((g.ntile + kThreads - 1) / kThreads), (unsigned)cf);
+            ScopedTiming timing(KIND_SVD, cx);
+#define OFMK_SVD8_LAUNCH(AL, MD) OFMK_TIMED_LAUNCH(timing, (svd8_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
+            if (mode == SVD_DETECT) { if (al) OFMK_SVD8_LAUNCH(true, SVD_DETECT); else OFMK_SVD8_LAUNCH(false, SVD_DETECT); }
+            else if (mode == SVD_EMBED) { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED); else OFMK_SVD8_LAUNCH(false, SVD_EMBED); }
+            else { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED_VERIFY); else OFMK_SVD8_LAUNCH(false, SVD_EMBED_VERIFY); }
+#undef OFMK_SVD8_LAUNCH
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (mode != SVD_DETECT && in != out && (Hc != H || Wc != W)) {
+        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W, Hc, Wc);
+        HIP_TRY(hipGetLastError());
+    }
+    return OFMK_OK;
+}
+
+int check_blk(int blk) {
+    if (blk != 4 && blk != 8)
+        return fail(OFMK_E_ARG, "blk must be 4 (the reference's default) or 8%s");
+    return OFMK_OK;
+}
+
+Svd8Args to_args8(const SvdArgs &a, int H, int W) {
+    Svd8Args b;
+    memset(&b, 0, sizeof(b));
+    b.wm = a.wm; b.wm_row = a.wm_row; b.n_wm = a.n_wm; b.counts = a.counts; b.bits = a.bits;
+    b.N = a.N; b.N8 = (int)((long long)H * W / 256); b.L = a.L;
+    for (int k = 0; k < 3; ++k) b.scales[k] = a.scales[k];
+    return b;
 }
 
 // ---- planar YUV 4:2:0 (I420 / NV12) -------------------------------------------------------------
@@ -620,61 +679,77 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, c
 }
 
 int ofmk_svd_embed_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
-                        const int32_t *wm_row, const double *scales, void *stream, const ofmk_opts *opts) {
+                        const int32_t *wm_row, const double *scales, int blk, void *stream, const ofmk_opts *opts) {
     if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
+    if ((rc = check_blk(blk))) return rc;
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.N = (int)((long long)H * W / 64); a.L = 1;
+    if (blk == 8) return launch_svd8_rgb8(in, out, n, H, W, SVD_EMBED, to_args8(a, H, W), make_ctx(stream, opts));
     return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED, a, make_ctx(stream, opts));
 }
 
 // scales[1] <= 0: the reference's decoder returns channel 1's (never written) bit array: all zeros
-int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales, int32_t *counts, uint8_t *bits,
+int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const double *scales, int blk, int32_t *counts, uint8_t *bits,
                          void *stream, const ofmk_opts *opts) {
     if (int orc = check_opts(opts)) return orc;
     int rc = check_detect_args(in, n, H, W, L, counts, bits);
     if (rc) return rc;
+    if ((rc = check_blk(blk))) return rc;
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, true))) return rc;
     a.counts = counts; a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = L;
+    const size_t bits_per_frame = blk == 8 ? (size_t)((long long)H * W / 256) : (size_t)a.N;     // dwt_dct_svd_decoder.py:14
     if (!(a.scales[1] > 0.f)) {
         hipStream_t s = static_cast<hipStream_t>(stream);
         if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
-        if (bits) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
+        if (bits) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * bits_per_frame, s));
         return OFMK_OK;
     }
+    if (blk == 8) return launch_svd8_rgb8(in, nullptr, n, H, W, SVD_DETECT, to_args8(a, H, W), make_ctx(stream, opts));
     return launch_svd_rgb8(in, nullptr, n, H, W, SVD_DETECT, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm,
-                               const int32_t *wm_row, const double *scales, int L, int32_t *counts, uint8_t *bits,
+                               const int32_t *wm_row, const double *scales, int blk, int L, int32_t *counts, uint8_t *bits,
                                void *stream, const ofmk_opts *opts) {
     if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(in, out, n, H, W, wm, n_wm);
     if (rc) return rc;
+    if ((rc = check_blk(blk))) return rc;
     if ((rc = check_detect_args(out, n, H, W, L, counts, bits))) return rc;
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.counts = counts; a.bits = bits;
     a.N = (int)((long long)H * W / 64); a.L = L;
+    if (blk == 8) return launch_svd8_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, to_args8(a, H, W), make_ctx(stream, opts));
     return launch_svd_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, a, make_ctx(stream, opts));
 }
 
 int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
-                           const double *scales, void *stream, const ofmk_opts *opts) {
+                           const double *scales, int blk, void *stream, const ofmk_opts *opts) {
     if (int orc = check_opts(opts)) return orc;
     int rc = check_embed_args(yuv, yuv, n, H, W, wm, n_wm);
     if (rc) return rc;
+    if ((rc = check_blk(blk))) return rc;
     if (n > kMaxChunk) return fail(OFMK_E_ARG, "too many frames%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.N = (int)((long long)H * W / 64); a.L = 1;
+    if (blk == 8) {
+        const Geom8 g8 = make_geom8(H, W);
+        if (g8.ntile > 0)
+            hipLaunchKernelGGL((svd8_yuv32f_kernel<SVD_EMBED>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0,
+                               static_cast<hipStream_t>(stream), yuv, g8, to_args8(a, H, W));
+        HIP_TRY(hipGetLastError());
+        return OFMK_OK;
+    }
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
@@ -683,21 +758,32 @@ int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, i
     return OFMK_OK;
 }
 
-int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, uint8_t *bits, void *stream,
+int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *scales, int blk, uint8_t *bits, void *stream,
                            const ofmk_opts *opts) {
     if (int orc = check_opts(opts)) return orc;
     int rc = check_dims(n, H, W);
     if (rc) return rc;
+    if ((rc = check_blk(blk))) return rc;
     if (!yuv || !bits) return fail(OFMK_E_ARG, "null pointer%s");
     if (n > kMaxChunk) return fail(OFMK_E_ARG, "too many frames%s");
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, true))) return rc;
     a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (blk == 8) {                                       // bits: [n][H*W/256] (dwt_dct_svd_decoder.py:14)
+        const Geom8 g8 = make_geom8(H, W);
+        const Svd8Args a8 = to_args8(a, H, W);
+        if (a8.N8 > g8.ntile || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a8.N8, s));
+        if (!(a.scales[1] > 0.f) || g8.ntile == 0) return OFMK_OK;
+        hipLaunchKernelGGL((svd8_yuv32f_kernel<SVD_DETECT>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0, s,
+                           const_cast<float *>(yuv), g8, a8);
+        HIP_TRY(hipGetLastError());
+        return OFMK_OK;
+    }
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.N > g.nblk || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
     if (!(a.scales[1] > 0.f)) return OFMK_OK;
     hipLaunchKernelGGL((svd_yuv32f_kernel<SVD_DETECT>), block_grid(g, n), dim3(kThreads), 0, s, const_cast<float *>(yuv), g, a);

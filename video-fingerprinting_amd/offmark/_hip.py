@@ -46,11 +46,11 @@ SIGNATURES = {
     "ofmk_debug_planes": (_i32, [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _op]),
     "ofmk_stage_analyze_rgb8": (_i32, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _op]),
     "ofmk_stage_mark_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
-    "ofmk_svd_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp, _op]),
-    "ofmk_svd_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _dp, _vp, _vp, _vp, _op]),
-    "ofmk_svd_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _vp, _vp, _vp, _op]),
-    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _vp, _op]),
-    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _dp, _vp, _vp, _op]),
+    "ofmk_svd_embed_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _vp, _op]),
+    "ofmk_svd_detect_rgb8": (_i32, [_vp, _i32, _i32, _i32, _i32, _dp, _i32, _vp, _vp, _vp, _op]),
+    "ofmk_svd_embed_detect_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _i32, _vp, _vp, _vp, _op]),
+    "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _vp, _op]),
+    "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _dp, _i32, _vp, _vp, _op]),
     "ofmk_payloads_from_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _op]),
     "ofmk_embed_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
     "ofmk_detect_yuv420": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),

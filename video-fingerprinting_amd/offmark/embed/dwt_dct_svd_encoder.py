@@ -2,9 +2,10 @@
 (reference src/offmark/embed/dwt_dct_svd_encoder.py:5-45): DwtDctSvdEncoder(key=None,
 scales=[0,15,0], blk=4), read_wm(wm), wm_capacity(frame_shape), encode(yuv) (mutates and returns).
 This is the codec tests/mark.py constructs.  Any per-channel ``scales`` are supported (every channel with a
-positive scale is marked with the same watermark, dwt_dct_svd_encoder.py:19-26); ``blk`` must be 4: with
-another block size the reference's loop count (row*col/4/blk^2) no longer matches its own capacity
-(row*col//64, dwt_dct_svd_encoder.py:14-17) and it either leaves watermark bits unused or indexes past them.
+positive scale is marked with the same watermark, dwt_dct_svd_encoder.py:19-26).  ``blk`` is 4 (the default: 8x8
+pixel tiles, one watermark bit per tile) or 8 (16x16 pixel tiles: tile c takes wm[c], so the first quarter of the
+(1, row*col//64) watermark is used, dwt_dct_svd_encoder.py:29-40).  Smaller blocks index past the reference's own
+watermark (its capacity stays row*col//64, dwt_dct_svd_encoder.py:14-17); larger ones are not built.
 No CPU fallback."""
 import numpy as np
 
@@ -15,9 +16,9 @@ def _check_scales(scales, blk, need_a_mark=True):
     scales = [float(x) for x in scales]
     if len(scales) != 3:
         raise ValueError("scales needs three entries (one per YUV channel); got %r" % (scales,))
-    if blk != 4:
-        raise NotImplementedError("the HIP DwtDctSvd codec implements blk=4 (the reference's default, the only value "
-                                  "for which its capacity and its block loop agree); got blk=%r" % (blk,))
+    if blk not in (4, 8):
+        raise NotImplementedError("the HIP DwtDctSvd codec implements blk=4 (the reference's default) and blk=8; smaller blocks "
+                                  "index past the reference's own watermark, larger ones are not built; got blk=%r" % (blk,))
     for x in scales:
         # the same rule as the C ABI (offmark_kernels.hip: set_scales): decided on the float32 value the kernels use
         if not np.isfinite(x) or (x > 0 and not np.float32(x) >= np.float32(1e-3)):
@@ -67,7 +68,7 @@ class DwtDctSvdEncoder:
         t = self.engine.torch
         h, w, _ = yuv.shape
         dev = t.from_numpy(np.ascontiguousarray(yuv)).to(self.engine.device).unsqueeze(0)
-        self.engine.svd_encode_yuv(dev, self._device_wm(h * w // 64), scales=self._scales)
+        self.engine.svd_encode_yuv(dev, self._device_wm(h * w // 64), scales=self._scales, blk=self.blk)
         back = dev[0].cpu().numpy()
         for ch in range(3):
             if self._scales[ch] > 0:
@@ -78,4 +79,4 @@ class DwtDctSvdEncoder:
         """frames: CUDA uint8 [n, H, W, 3]: the whole reference frame step (embedder.py:33-39) on device."""
         n, h, w, _ = frames.shape
         wm = wm_table if wm_table is not None else self._device_wm(h * w // 64)
-        return self.engine.svd_embed(frames, wm, scales=self._scales, wm_row=wm_rows, out=out)
+        return self.engine.svd_embed(frames, wm, scales=self._scales, wm_row=wm_rows, out=out, blk=self.blk)

@@ -283,53 +283,58 @@ class DctEngine:
         return counts, bits
 
     # -- DwtDctSvd codec (one pass, no workspace) ---------------------------------------------------
-    def svd_embed(self, frames, wm, scale=15, wm_row=None, out=None, scales=None):
+    @staticmethod
+    def svd_bits_per_frame(H, W, blk=4):
+        """Length of the decoder's bit array (dwt_dct_svd_decoder.py:14): row*col//4//(blk*blk)."""
+        return H * W // 4 // (blk * blk)
+
+    def svd_embed(self, frames, wm, scale=15, wm_row=None, out=None, scales=None, blk=4):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
         _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
-                                                _hip.ptr(rows), _hip.scales3(scale, scales), _hip.current_stream(),
+                                                _hip.ptr(rows), _hip.scales3(scale, scales), int(blk), _hip.current_stream(),
                                                 _hip.opts_ref(self.opts)))
         return out
 
-    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None):
+    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None, blk=4):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
-        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
-        _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), _hip.scales3(scale, scales), counts.data_ptr(),
+        bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
+        _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), _hip.scales3(scale, scales), int(blk), counts.data_ptr(),
                                                  _hip.ptr(bits), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return counts, bits
 
-    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None):
+    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None, blk=4):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
-        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
+        bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
-                                                       wm.shape[0], _hip.ptr(rows), _hip.scales3(scale, scales), int(L),
+                                                       wm.shape[0], _hip.ptr(rows), _hip.scales3(scale, scales), int(blk), int(L),
                                                        counts.data_ptr(), _hip.ptr(bits), _hip.current_stream(),
                                                        _hip.opts_ref(self.opts)))
         return out, counts, bits
 
-    def svd_encode_yuv(self, yuv, wm, scale=15, scales=None):
+    def svd_encode_yuv(self, yuv, wm, scale=15, scales=None, blk=4):
         t = self.torch
         n, H, W = self._check_frames(yuv, t.float32)
         wm = self._wm(wm, H * W // 64)
         _hip.check(self.lib.ofmk_svd_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], None,
-                                                   _hip.scales3(scale, scales), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                   _hip.scales3(scale, scales), int(blk), _hip.current_stream(), _hip.opts_ref(self.opts)))
         return yuv
 
-    def svd_decode_yuv(self, yuv, scale=15, scales=None):
+    def svd_decode_yuv(self, yuv, scale=15, scales=None, blk=4):
         t = self.torch
         n, H, W = self._check_frames(yuv, t.float32)
-        bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device)
-        _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, _hip.scales3(scale, scales), bits.data_ptr(),
+        bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device)
+        _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, _hip.scales3(scale, scales), int(blk), bits.data_ptr(),
                                                    _hip.current_stream(), _hip.opts_ref(self.opts)))
         return bits
 
