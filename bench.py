@@ -572,7 +572,7 @@ def main():
         extra["dwtdctsvd_blk8"] = dict(value=round(world * n * k4 / el5, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el5 / k4, 4),
                                        payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
                                        algorithmic_GBps=round(n * k4 * 6 * H * W / el5 / 1e9, 1),
-                                       note="DwtDctSvd(blk=8) embed + verify + payloads (not tuned: the tile is read twice)")
+                                       note="DwtDctSvd(blk=8) embed + verify + payloads (16x16 pixel tiles; the tile is read twice, the second time from cache)")
 
     if rank != 0:
         if world > 1:

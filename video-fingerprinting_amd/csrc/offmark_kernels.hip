@@ -187,6 +187,18 @@ bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block 
     return W % 8 == 0 && (uintptr_t)p % need == 0;
 }
 
+// in -> out for the pixels outside the first Hc rows x Wc columns (frames in chunks of gridDim.y)
+void launch_copy_fringe(const uint8_t *in, uint8_t *out, int n, int H, int W, int Hc, int Wc, hipStream_t s) {
+    const size_t fringe = (size_t)(H - Hc) * W * 3 + (size_t)Hc * (W - Wc) * 3;
+    if (fringe == 0) return;
+    const unsigned gx = (unsigned)((fringe + 256 * 4 - 1) / (256 * 4));
+    for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
+        const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
+        const size_t fo = (size_t)f0 * H * W * 3;
+        hipLaunchKernelGGL(copy_fringe_kernel, dim3(gx < 1024 ? gx : 1024, (unsigned)cf), dim3(256), 0, s, in + fo, out + fo, H, W, Hc, Wc);
+    }
+}
+
 // zero_counts (optional): [n][L] position sums of these frames, cleared by the kernel for a finalize that follows
 int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, const Ctx &cx,
                    int32_t *zero_counts = nullptr, int L = 0) {
@@ -255,7 +267,7 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
     }
     HIP_TRY(hipGetLastError());
     if (in != out && (H % 8 || W % 8)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W, (H / 8) * 8, (W / 8) * 8);
+        launch_copy_fringe(in, out, n, H, W, (H / 8) * 8, (W / 8) * 8, s);
         HIP_TRY(hipGetLastError());
     }
     return OFMK_OK;
@@ -352,7 +364,7 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
     }
     HIP_TRY(hipGetLastError());
     if (mode != SVD_DETECT && in != out && (H % 8 || W % 8)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W, (H / 8) * 8, (W / 8) * 8);
+        launch_copy_fringe(in, out, n, H, W, (H / 8) * 8, (W / 8) * 8, s);
         HIP_TRY(hipGetLastError());
     }
     return OFMK_OK;
@@ -395,7 +407,7 @@ int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int m
         HIP_TRY(hipGetLastError());
     }
     if (mode != SVD_DETECT && in != out && (Hc != H || Wc != W)) {
-        hipLaunchKernelGGL(copy_fringe_kernel, dim3(512), dim3(256), 0, s, in, out, n, H, W, Hc, Wc);
+        launch_copy_fringe(in, out, n, H, W, Hc, Wc, s);
         HIP_TRY(hipGetLastError());
     }
     return OFMK_OK;
