@@ -461,12 +461,15 @@ def main():
         with torch.cuda.stream(side):
             gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=equal, force=grouped)
         torch.cuda.synchronize()
+    for lane in lanes:
+        lane["eng"].opts = opts_timed                       # every kernel of the timed steps carries its own event pair ...
     if a.warmup:
-        run(a.warmup)
+        run(a.warmup)                                       # ... and so do the warm-up steps: they are the timed steps' twins
+        if timing:
+            torch.cuda.synchronize()
+            timing.collect()                                # rewind the event pool: the durations reported are the timed region's
     DOMINANT = ("analyze" if mode == "detect" else "mark" if a.separate_detect else "mark_fused") if a.codec == "dct" else "svd"
 
-    for lane in lanes:
-        lane["eng"].opts = opts_timed                       # every kernel of the timed steps carries its own event pair
     elapsed, votes, mine = timed(a.steps)
     host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in host_s.items()}
     for lane in lanes:
