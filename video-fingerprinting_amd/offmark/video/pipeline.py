@@ -56,7 +56,9 @@ def pinned_empty(shape, dtype=np.uint8) -> np.ndarray:
     """ndarray over freshly allocated page-locked memory (torch's caching host allocator owns it; the array keeps
     the tensor alive)."""
     import torch
-    t = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name)).pin_memory()
+    # allocated page-locked in the first place (not .pin_memory(): that allocates pageable memory, touches it and copies it);
+    # blocks come back from torch's caching host allocator, so a second pipeline run does not pay hipHostMalloc again
+    t = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True)
     return t.numpy()
 
 
