@@ -177,6 +177,18 @@ class _ReadAhead(threading.Thread):
             pass
 
 
+def _tensor_over(array):
+    """torch view of a host array for a DMA copy.  A reader may hand out read-only arrays (np.frombuffer over a pipe's
+    bytes): torch warns that writes through the tensor would be undefined -- it is only ever a copy SOURCE here."""
+    import warnings
+    import torch
+    if array.flags.writeable:
+        return torch.from_numpy(array)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(array)
+
+
 class _Slot:
     def __init__(self, torch, device, batch, in_shape, in_dtype, out_shape, out_dtype):
         self.dev_in = torch.empty((batch,) + tuple(in_shape), dtype=in_dtype, device=device)
@@ -259,7 +271,7 @@ class StagedPipeline:
                     landing = slot.host_out[:m]
                 with t.cuda.stream(s_up):
                     s_up.wait_event(slot.ev_k)                 # the kernels that last read this device buffer are done
-                    slot.dev_in[:m].copy_(t.from_numpy(src), non_blocking=True)
+                    slot.dev_in[:m].copy_(_tensor_over(src), non_blocking=True)
                     slot.ev_in.record()
                 with t.cuda.stream(s_k):
                     s_k.wait_event(slot.ev_in)
