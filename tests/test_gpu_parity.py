@@ -1002,6 +1002,8 @@ def test_bench_configs_run_at_one_gpu(config, extra):
     assert line["scaling"] == ("strong" if config in (4, 5) else "weak")
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"]
+    if config in (2, 3):
+        assert line["value_two_streams"] > 0 and line["two_streams"]["votes_ok"]
     assert line["hbm_copy_GBps"] > 1000 and line["hbm_read_GBps"] > 1000      # sanity only: a rate, not a ranking
     if config == 5:        # BASELINE configs[4]: the attack suite is reported next to the line; clean and noisy leaks must resolve
         atk = line["attacks"]
