@@ -67,3 +67,63 @@ def golden_cases():
 def svd_golden_cases():
     """DwtDctSvd codec cases."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("svd_") and f.endswith(".npz"))
+
+
+FAKE_FFMPEG = r'''#!/usr/bin/env python3
+"""Test double for the ffmpeg / ffprobe binaries (neither exists on the test boxes): a "video file" is a one-line header
+`W H PIXFMT` followed by raw frames.  Only what offmark.video.frame_reader.FileDecoder / frame_writer.FileEncoder put on
+the command line is understood; pixel formats are passed through, never converted."""
+import json, os, sys
+argv = sys.argv[1:]
+name = os.path.basename(sys.argv[0])
+def header(path):
+    with open(path, "rb") as f:
+        w, h, fmt = f.readline().split()
+        return int(w), int(h), fmt.decode(), f.tell()
+if name == "ffprobe":
+    w, h, fmt, _ = header(argv[-1])
+    print(json.dumps({"streams": [{"codec_type": "audio"}, {"codec_type": "video", "width": w, "height": h, "pix_fmt": fmt}]}))
+    sys.exit(0)
+src = argv[argv.index("-i") + 1]
+if src != "pipe:":                                  # decode: ffmpeg -i file -f rawvideo -pix_fmt X pipe:
+    w, h, fmt, off = header(src)
+    want = argv[len(argv) - 1 - argv[::-1].index("-pix_fmt") + 1]
+    assert argv[-1] == "pipe:" and want == fmt, (argv, fmt)
+    with open(src, "rb") as f:
+        f.seek(off)
+        while True:
+            chunk = f.read(1 << 16)
+            if not chunk:
+                break
+            sys.stdout.buffer.write(chunk)
+else:                                               # encode: ffmpeg -f rawvideo -pix_fmt X -s WxH -i pipe: -pix_fmt yuv420p out
+    fmt = argv[argv.index("-pix_fmt") + 1]
+    w, h = argv[argv.index("-s") + 1].split("x")
+    with open(argv[-1], "wb") as f:
+        f.write(f"{w} {h} {fmt}\n".encode())
+        while True:
+            chunk = sys.stdin.buffer.read(1 << 16)
+            if not chunk:
+                break
+            f.write(chunk)
+'''
+
+
+@pytest.fixture
+def fake_ffmpeg(tmp_path, monkeypatch):
+    """Puts test doubles named ffmpeg / ffprobe first on PATH; returns a function that writes a "video file"."""
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    for name in ("ffmpeg", "ffprobe"):
+        path = bindir / name
+        path.write_text(FAKE_FFMPEG.replace("#!/usr/bin/env python3", "#!" + sys.executable))
+        path.chmod(0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+
+    def write_video(path, frames, pix_fmt="rgb24"):
+        h, w = (frames.shape[1], frames.shape[2]) if pix_fmt == "rgb24" else (frames.shape[1] * 2 // 3, frames.shape[2])
+        with open(path, "wb") as f:
+            f.write(f"{w} {h} {pix_fmt}\n".encode())
+            f.write(np.ascontiguousarray(frames, dtype=np.uint8).tobytes())
+        return str(path)
+    return write_video

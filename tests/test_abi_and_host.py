@@ -335,3 +335,38 @@ def test_pipeline_host_side_read_ahead_and_writer_protocol():
     buf[:] = 0                                                   # the caller reuses its buffer: the writer kept a copy
     assert np.array_equal(np.stack(w.frames), frames[:4])
     assert queue.Queue                                           # (imported for the timeout above)
+
+
+def test_file_decoder_and_encoder_plumbing_with_a_stand_in_ffmpeg(fake_ffmpeg, tmp_path):
+    """FileDecoder / FileEncoder (reference frame_reader.py:28-69, frame_writer.py:23-50) drive `ffmpeg` child processes.
+    No ffmpeg exists on the test boxes, so a test double on PATH (tests/conftest.py: raw frames behind a one-line header,
+    formats passed through) stands in for the binaries: what is tested is this package's plumbing -- the probe, the command
+    lines, frame sizes for rgb24 and yuv420p, read(), read_batch(), read_batch_into() straight from the pipe, end of
+    stream, write() / write_batch() and close()."""
+    from offmark.video.frame_reader import FileDecoder
+    from offmark.video.frame_writer import FileEncoder
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, (7, 16, 24, 3), dtype=np.uint8)
+    path = fake_ffmpeg(tmp_path / "in.raw", frames)
+    r = FileDecoder(path)
+    assert (r.width, r.height, r.pix_fmt) == (24, 16, "rgb24")
+    assert np.array_equal(r.read(), frames[0])
+    assert np.array_equal(r.read_batch(2), frames[1:3])
+    buf = np.empty((3, 16, 24, 3), np.uint8)
+    assert r.read_batch_into(buf) == 3 and np.array_equal(buf, frames[3:6])
+    assert r.read_batch_into(buf) == 1 and np.array_equal(buf[0], frames[6])       # ragged tail
+    assert r.read_batch_into(buf) == 0 and r.read() is None
+    r.close()
+    planes = rng.integers(0, 256, (4, 24, 24), dtype=np.uint8)                     # 16x24 yuv420p frames: [H*3/2, W]
+    rp = FileDecoder(fake_ffmpeg(tmp_path / "p.raw", planes, "yuv420p"), pix_fmt="yuv420p")
+    assert (rp.width, rp.height) == (24, 16) and np.array_equal(rp.read_batch(9), planes)
+    rp.close()
+    out = str(tmp_path / "out.raw")
+    w = FileEncoder(out, 24, 16)
+    w.write(frames[0])
+    w.write_batch(frames[1:4])
+    w.write(frames[4][:, ::-1][:, ::-1])                                           # a non-contiguous view is written whole too
+    w.close()
+    back = FileDecoder(out)
+    assert np.array_equal(back.read_batch(99), frames[:5])
+    back.close()

@@ -267,3 +267,49 @@ def test_timing_options_do_not_dangle(eng):
     assert e2.opts._timing.collect()["mark"]["launches"] == 1
     import torch
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("pix_fmt", ["rgb24", "yuv420p"])
+def test_mark_and_detect_drivers_over_file_readers_and_writers(eng, fake_ffmpeg, tmp_path, pix_fmt):
+    """The call sequence of tests/mark.py:18-40 and tests/detect.py:17-31 -- FileDecoder -> Embedder -> FileEncoder, then
+    FileDecoder -> Extractor -- with the ffmpeg child processes replaced by the test double of tests/conftest.py (no ffmpeg on
+    the boxes; the shape of the bundled clip: 320x240, 209 frames).  The pipe is read straight into the pipeline's page-locked
+    staging (read_batch_into); what lands in the written "file" equals one direct batch call, every frame decodes to the
+    payload.  yuv420p: the planes travel instead of rgb24 (the reference's open question, frame_reader.py:27)."""
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder
+    from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder
+    from offmark.generator.shuffler import Shuffler
+    from offmark.video.embedder import Embedder
+    from offmark.video.extractor import Extractor
+    from offmark.video.frame_reader import FileDecoder
+    from offmark.video.frame_writer import FileEncoder
+    h, w, n = 240, 320, 209
+    base = [orc.synthetic_frame(h, w, 1001 + i) for i in range(11)]
+    rgb = np.stack([np.roll(base[i % 11], 8 * (i // 11), axis=1) for i in range(n)])
+    clip = rgb if pix_fmt == "rgb24" else eng.rgb_to_yuv420(cuda(rgb)).cpu().numpy().reshape(n, h * 3 // 2, w)
+    in_file, out_file = fake_ffmpeg(tmp_path / "in.raw", clip, pix_fmt), str(tmp_path / "marked.raw")
+    payload = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    r = FileDecoder(in_file, pix_fmt=pix_fmt)
+    wr = FileEncoder(out_file, r.width, r.height, pix_fmt=pix_fmt)
+    frame_embedder = DwtDctSvdEncoder()
+    capacity = frame_embedder.wm_capacity((r.height, r.width, 3))
+    wm = Shuffler(key=0).generate_wm(payload, capacity)
+    frame_embedder.read_wm(wm)
+    video_embedder = Embedder(r, frame_embedder, wr)
+    video_embedder.start()
+    assert video_embedder.frames_marked == n
+    rd = FileDecoder(out_file, pix_fmt=pix_fmt)
+    written = rd.read_batch(n + 5)
+    rd.close()
+    if pix_fmt == "rgb24":
+        want = frame_embedder.encode_frames_u8(cuda(rgb)).cpu().numpy()
+    else:
+        planes = cuda(clip.reshape(n, -1))
+        want = eng.rgb_to_yuv420(frame_embedder.encode_frames_u8(eng.yuv420_to_rgb(planes, h, w))).cpu().numpy().reshape(clip.shape)
+    assert written.shape == clip.shape and np.array_equal(written, want)
+    degenerator = DeShuffler(key=0)
+    degenerator.set_shape(payload.shape)
+    video_extractor = Extractor(FileDecoder(out_file, pix_fmt=pix_fmt), DwtDctSvdDecoder(), degenerator)
+    video_extractor.start()
+    assert len(video_extractor.patterns) == n and all(np.array_equal(p, payload) for p in video_extractor.patterns)
