@@ -11,7 +11,8 @@ Tolerances (the reference pins none for this path).  Budgets are ~
   payload after DeShuffler ............ bit-exact
   raw per-block bits .................. <= 1e-4 of the blocks (floor: 1 block) vs oracle (ulp-level threshold flips)
   Y DC, C21 ........................... <= 1e-3 absolute on 0..255-scale data
-  luminance / texture masks ........... equal to 1e-9 relative except on <= 1e-4 threshold-flip blocks
+  luminance / texture masks ........... within 2e-6 absolute (float32 rounding of the block mean / of eh carried through
+                                        the float64 formulas) except on <= 1e-4 threshold-flip blocks
   marked u8 pixels .................... <= 1 LSB, on <= 1e-5 of the samples (floor: 1 sample), over
                                         "sign-determined" blocks
 
