@@ -493,3 +493,23 @@ def test_extreme_content_against_oracle(eng, codec):
         assert (b[:nb] != ref_bits[:nb])[readable].sum() <= 1, (name, codec, int((b[:nb] != ref_bits[:nb])[readable].sum()))
         if (b != ref_bits).sum() == 0:
             assert np.array_equal(deg.degenerate_counts(counts[0].cpu().numpy(), nbits), orc.deshuffle(ref_bits[None], 8, 0)), (name, codec)
+
+
+@pytest.mark.parametrize("blk", [4, 8])
+def test_svd_counts_for_long_payloads_use_the_global_atomic_path(eng, blk):
+    """Payload lengths beyond the LDS histogram (2048): counts[i] must still be the number of ones among bits[i::L]
+    (de_shuffler.py:17-18), also when L exceeds the number of bits a frame carries."""
+    frames = cuda(np.stack([orc.synthetic_frame(240, 320, 1001 + i) for i in range(3)]))
+    wm = cuda(np.random.default_rng(4).integers(0, 2, (1, 1200), dtype=np.uint8))
+    marked = eng.svd_embed(frames, wm, blk=blk)
+    for L in (8, 2048, 2049, 3000, 70000):
+        counts, bits = eng.svd_detect(marked, L, want_bits=True, blk=blk)
+        b = bits.cpu().numpy()
+        want = np.stack([[row[i::L].sum() for i in range(L)] for row in b]) if L <= 3000 else None
+        c = counts.cpu().numpy()
+        if want is not None:
+            assert np.array_equal(c, want), (blk, L)
+        else:
+            assert np.array_equal(c[:, : b.shape[1]], b) and not c[:, b.shape[1]:].any()       # every bit is alone in its position
+        o, c2, b2 = eng.svd_embed_detect(frames, wm, L, want_bits=True, blk=blk)
+        assert np.array_equal(c2.cpu().numpy(), c) and np.array_equal(b2.cpu().numpy(), b)
