@@ -7,7 +7,7 @@ forms:
                               page-locked memory (ArrayFrameWriter(capacity=...)): no host copy at either end
   rgb24 "pageable"            plain ndarray in, ArrayFrameWriter that copies every batch: two host copies per frame
                               (threaded), what a caller gets who changes nothing
-usage: python tools/plugin_pipeline_rate.py [frames] [batch]"""
+usage: python tools/plugin_pipeline_rate.py [frames] [batch] [forms, comma-separated: one DCT run of those forms only]"""
 import os
 import sys
 import time
@@ -80,7 +80,8 @@ def measure(n=400, B=50, H=1080, W=1920, reps=2, forms=("rgb24", "yuv420p", "pag
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-    for codec in ("dct", "dwtdctsvd"):
-        for form, v in measure(n, B, codec=codec).items():
+    only = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("rgb24", "yuv420p", "pageable")     # e.g. "rgb24" for a trace
+    for codec in (("dct",) if len(sys.argv) > 3 else ("dct", "dwtdctsvd")):
+        for form, v in measure(n, B, codec=codec, forms=only).items():
             print(f"{codec:9s} {form:15s}: Embedder {v['embedder_fps']:8.0f} frames/s ({v['GBps_each_way_embedder']} GB/s each way), "
                   f"Extractor {v['extractor_fps']:8.0f} frames/s, payloads ok: {v['payloads_ok']}")
