@@ -116,6 +116,18 @@ int main(void) {
     CHECK_HIP(hipStreamSynchronize(stream));
     ok &= payloads_ok(h_payload, "DwtDctSvd ofmk_svd_detect_rgb8 on the output");
 
+    /* the same codec with blk = 8 (16x16 pixel tiles): H*W/256 bits per frame, tile c carries wm[c] */
+    CHECK_OFMK(ofmk_svd_embed_detect_rgb8(d_in, d_out, N_FRAMES, H, W, d_wm, 1, NULL, scales, 8, L, d_counts, NULL, stream, NULL));
+    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, H * W / 256, d_perm, d_payload, stream, NULL));
+    CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    ok &= payloads_ok(h_payload, "DwtDctSvd blk=8 ofmk_svd_embed_detect_rgb8");
+    CHECK_OFMK(ofmk_svd_detect_rgb8(d_out, N_FRAMES, H, W, L, scales, 8, d_counts, NULL, stream, NULL));
+    CHECK_OFMK(ofmk_payloads_from_counts(d_counts, N_FRAMES, L, H * W / 256, d_perm, d_payload, stream, NULL));
+    CHECK_HIP(hipMemcpyAsync(h_payload, d_payload, sizeof(h_payload), hipMemcpyDeviceToHost, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    ok &= payloads_ok(h_payload, "DwtDctSvd blk=8 ofmk_svd_detect_rgb8 on the output");
+
     /* errors are return codes with a per-thread text, never aborts */
     const int rc = ofmk_detect_rgb8(d_out, N_FRAMES, 4, W, L, 20.0, d_counts, NULL, 0, d_ws, ws_bytes, stream, NULL);
     printf("a frame height of 4 is refused with code %d: %s\n", rc, ofmk_last_error());

@@ -1089,5 +1089,5 @@ def test_c_host_program_over_the_abi(tmp_path):
     build_abi_demo(exe)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    assert r.stdout.strip().endswith("abi_demo OK") and r.stdout.count("6 of 6 frames carry the payload") == 4
+    assert r.stdout.strip().endswith("abi_demo OK") and r.stdout.count("6 of 6 frames carry the payload") == 6
     assert "refused with code -1" in r.stdout
