@@ -134,6 +134,46 @@ __global__ __launch_bounds__(256) void pattern_coalesced_write(const uint8_t *__
     }
 }
 
+// The engine pattern with the workgroup -> tile mapping made XCD-aware.  Workgroups are dispatched round-robin over the 8 XCDs
+// in linear order (x fastest, then y), so by default XCD k gets every 8th 48 KiB tile.  MODE 1: XCD k walks ONE contiguous
+// eighth of the batch (consecutive workgroups of an XCD are neighbours in memory).  MODE 2: XCD k takes every 8th FRAME
+// (frame-contiguous per XCD).  Is the 24-byte-per-lane pattern's 15 % below the plain copy a DRAM-locality effect?
+template <int MODE>
+__global__ __launch_bounds__(256) void pattern_xcd(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int wb, int nblk,
+                                                   size_t frame_stride, int nf) {
+    const unsigned gx = gridDim.x, G = gx * (unsigned)nf;
+    const unsigned L = blockIdx.y * gx + blockIdx.x;
+    unsigned t;
+    if (MODE == 1) {
+        const unsigned per = (G + 7) / 8;
+        t = (L % 8) * per + L / 8;
+    } else {
+        const unsigned xcd = L % 8, i = L / 8;                 // i-th workgroup of this XCD
+        const unsigned fpx = ((unsigned)nf + 7) / 8;           // frames per XCD
+        const unsigned fl = i / gx, x = i % gx;
+        t = (fl * 8 + xcd) * gx + x;
+        if (fl >= fpx) return;
+    }
+    if (t >= G) return;
+    const int f = t / gx;
+    int c = (t % gx) * 256 + threadIdx.x;
+    if (c >= nblk) c = nblk - 1;
+    const int bi = c / wb, bj = c - bi * wb;
+    const size_t off = (size_t)f * frame_stride + ((size_t)bi * 8 * W + (size_t)bj * 8) * 3;
+    const int pitch = W * 3;
+    uint2 v[8][3];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint2 *q = reinterpret_cast<const uint2 *>(in + off + (size_t)r * pitch);
+        v[r][0] = q[0]; v[r][1] = q[1]; v[r][2] = q[2];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        uint2 *q = reinterpret_cast<uint2 *>(out + off + (size_t)r * pitch);
+        q[0] = v[r][0]; q[1] = v[r][1]; q[2] = v[r][2];
+    }
+}
+
 template <typename F>
 void timeit(const char *name, double bytes, F launch) {
     hipEvent_t e0, e1;
@@ -190,6 +230,9 @@ int main() {
         timeit("engine pattern copy, 4 WG/CU (LDS cap)", 2.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_var<256, false, false, 40000>), grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs); });
         timeit("engine pattern copy, 2 WG/CU (LDS cap)", 2.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_var<256, false, false, 80000>), grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs); });
         timeit("engine pattern copy, 1 WG/CU (LDS cap)", 2.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_var<256, false, false, 160000>), grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs); });
+        timeit("engine pattern copy, XCD-contiguous eighths", 2.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_xcd<1>), dim3(grid.x, grid.y + 1), dim3(256), 0, 0, in, out, W, wb, nblk, fs, nf); });
+        timeit("engine pattern copy, frames dealt to XCDs", 2.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_xcd<2>), dim3(grid.x, grid.y + 8), dim3(256), 0, 0, in, out, W, wb, nblk, fs, nf); });
+        timeit("engine pattern copy, 8 rows in flight (again)", 2.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_kernel<true, 8>), grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs, sink); });
         timeit("engine reads + coalesced 16-B stores", 2.0 * nf * fs, [&] { hipLaunchKernelGGL(pattern_coalesced_write, grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs); });
         timeit("engine pattern read, 8 rows in flight", 1.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_kernel<false, 8>), grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs, sink); });
         timeit("engine pattern read, 4 rows in flight", 1.0 * nf * fs, [&] { hipLaunchKernelGGL((pattern_kernel<false, 4>), grid, dim3(256), 0, 0, in, out, W, wb, nblk, fs, sink); });

@@ -169,8 +169,9 @@ int check_dims(int n, int H, int W) {
     return OFMK_OK;
 }
 
-Geom make_geom(int H, int W, const Workspace &ws) {
+Geom make_geom(int H, int W, const Workspace &ws, int frames = 0) {
     Geom g;
+    g.frames = frames;
     g.W = W;
     g.wb = W / 8;
     g.inv_wb = 1.0f / (float)g.wb;
@@ -181,6 +182,14 @@ Geom make_geom(int H, int W, const Workspace &ws) {
 }
 
 dim3 block_grid(const Geom &g, int n) { return dim3((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n); }
+
+// Linear grid of the frame kernels that order their tiles XCD-aware (common.hiph: xcd_tile): tiles x frames workgroups, padded
+// to a multiple of the 8 XCDs; the kernels take the frame count from their geometry argument.
+dim3 xcd_grid(int blocks_per_frame, int n) {
+    const unsigned tiles = (unsigned)((blocks_per_frame + kThreads - 1) / kThreads);
+    const unsigned long long G = (unsigned long long)tiles * (unsigned)n;
+    return dim3((unsigned)(((G + kXcds - 1) / kXcds) * kXcds));
+}
 
 bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block row starts on 8 B (u8) / 16 B (f32)
     const size_t need = elem == 1 ? 8 : 16;
@@ -206,8 +215,8 @@ int launch_analyze(const void *frames, int src, int n, int H, int W, const Works
     // one fill for both accumulator arrays (they are adjacent): ysum for this pass, ysum2 for a fused mark+verify
     // kernel that may follow -- one dispatch less per step than zeroing ysum2 in front of the mark kernel
     HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, s));
-    const Geom g = make_geom(H, W, ws);
-    const dim3 grid = block_grid(g, n);
+    const Geom g = make_geom(H, W, ws, n);
+    const dim3 grid = xcd_grid(g.nblk, n);
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
     ScopedTiming timing(KIND_ANALYZE, cx);
     if (src == SRC_RGB8) {
@@ -244,8 +253,8 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
                      double alpha, const Workspace &ws, bool fused, const Ctx &cx, bool ysum2_is_zero = false) {
     hipStream_t s = cx.s;
     if (fused && !ysum2_is_zero) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
-    const Geom g = make_geom(H, W, ws);
-    const dim3 grid = block_grid(g, n);
+    const Geom g = make_geom(H, W, ws, n);
+    const dim3 grid = xcd_grid(g.nblk, n);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
     MarkArgs m;
     m.rec = ws.rec;
@@ -351,9 +360,11 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
         if (b.wm_row) b.wm_row += f0;
         if (b.counts) b.counts += (size_t)f0 * a.L;
         if (b.bits) b.bits += (size_t)f0 * a.N;
-        const dim3 grid = block_grid(g, cf);
+        Geom gc = g;
+        gc.frames = cf;
+        const dim3 grid = xcd_grid(g.nblk, cf);
         ScopedTiming timing(KIND_SVD, cx);
-#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
+#define OFMK_SVD_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, gc, b)
         const bool multi = a.scales[0] > 0.f || a.scales[2] > 0.f || !(a.scales[1] > 0.f);      // anything but the default [0, s, 0]
         if (mode == SVD_DETECT) { if (al) OFMK_SVD_LAUNCH(true, SVD_DETECT, false); else OFMK_SVD_LAUNCH(false, SVD_DETECT, false); }
         else if (mode == SVD_EMBED && !multi) { if (al) OFMK_SVD_LAUNCH(true, SVD_EMBED, false); else OFMK_SVD_LAUNCH(false, SVD_EMBED, false); }
@@ -377,6 +388,7 @@ Geom8 make_geom8(int H, int W) {
     g.wt = ((W / 4) * 2) / 8;
     g.inv_wt = g.wt ? 1.0f / (float)g.wt : 0.f;
     g.ntile = (((H / 4) * 2) / 8) * g.wt;
+    g.frames = 0;
     g.frame_stride = (size_t)H * W * 3;
     return g;
 }
@@ -396,9 +408,11 @@ int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int m
             if (b.wm_row) b.wm_row += f0;
             if (b.counts) b.counts += (size_t)f0 * a.L;
             if (b.bits) b.bits += (size_t)f0 * a.N8;
-            const dim3 grid((unsigned)((g.ntile + kThreads - 1) / kThreads), (unsigned)cf);
+            Geom8 gc = g;
+            gc.frames = cf;
+            const dim3 grid = xcd_grid(g.ntile, cf);
             ScopedTiming timing(KIND_SVD, cx);
-#define OFMK_SVD8_LAUNCH(AL, MD) OFMK_TIMED_LAUNCH(timing, (svd8_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, g, b)
+#define OFMK_SVD8_LAUNCH(AL, MD) OFMK_TIMED_LAUNCH(timing, (svd8_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, gc, b)
             if (mode == SVD_DETECT) { if (al) OFMK_SVD8_LAUNCH(true, SVD_DETECT); else OFMK_SVD8_LAUNCH(false, SVD_DETECT); }
             else if (mode == SVD_EMBED) { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED); else OFMK_SVD8_LAUNCH(false, SVD_EMBED); }
             else { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED_VERIFY); else OFMK_SVD8_LAUNCH(false, SVD_EMBED_VERIFY); }
@@ -454,7 +468,7 @@ int launch_analyze_yuv420(const uint8_t *frames, int layout, int n, int H, int W
                           int32_t *zero_counts = nullptr, int L = 0) {
     HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, cx.s));
     const PGeom g = make_pgeom(layout, H, W, ws.plane);
-    const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);
+    const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);     // 2-D grid: the planar kernels gain nothing from the XCD order
     ScopedTiming timing(KIND_PLANAR, cx);
     if (layout == OFMK_YUV_I420) OFMK_TIMED_LAUNCH(timing, analyze_yuv420_kernel<FMT_I420>, grid, dim3(kThreads), 0, cx.s, frames, g, ws.rec, ws.ysum, zero_counts, L);
     else OFMK_TIMED_LAUNCH(timing, analyze_yuv420_kernel<FMT_NV12>, grid, dim3(kThreads), 0, cx.s, frames, g, ws.rec, ws.ysum, zero_counts, L);
