@@ -370,3 +370,11 @@ def test_file_decoder_and_encoder_plumbing_with_a_stand_in_ffmpeg(fake_ffmpeg, t
     back = FileDecoder(out)
     assert np.array_equal(back.read_batch(99), frames[:5])
     back.close()
+
+
+def test_pipeline_batches_are_bounded_in_bytes():
+    from offmark.video.pipeline import batch_size, frame_shape
+    assert batch_size(64, frame_shape("rgb24", 1080, 1920)) == 64            # 398 MB: the caller's choice stands
+    assert batch_size(64, frame_shape("rgb24", 2160, 3840)) == 21            # 4K: 64 frames would be 1.6 GB per buffer, 9 buffers
+    assert batch_size(64, frame_shape("yuv420p", 2160, 3840)) == 43
+    assert batch_size(0, (8, 8, 3)) == 1 and batch_size(5, (8, 8, 3)) == 5

@@ -77,8 +77,8 @@ class Embedder:
             else:
                 eng.rgb_to_yuv420(enc.encode_frames_u8(rgb), layout=pl.PLANAR_LAYOUT[out_fmt], out=dev_out.view(m, -1))
 
-        pipe = pl.StagedPipeline(eng.device, reader, self.batch_frames, pl.frame_shape(in_fmt, H, W),
-                                 pl.frame_shape(out_fmt, H, W), np.uint8)
+        pipe = pl.StagedPipeline(eng.device, reader, pl.batch_size(self.batch_frames, pl.frame_shape(in_fmt, H, W)),
+                                 pl.frame_shape(in_fmt, H, W), pl.frame_shape(out_fmt, H, W), np.uint8)
         try:
             pipe.run(process, pl.WriterSink(self.frame_writer))
         finally:

@@ -81,7 +81,8 @@ class Extractor:
                     outer.patterns.append(out)
                     logger.info(out)
 
-        pl.StagedPipeline(eng.device, reader, self.batch_frames, pl.frame_shape(fmt, H, W), (L,), np.int32).run(process, Sink())
+        pl.StagedPipeline(eng.device, reader, pl.batch_size(self.batch_frames, pl.frame_shape(fmt, H, W)), pl.frame_shape(fmt, H, W),
+                          (L,), np.int32).run(process, Sink())
         logger.info("End of input stream")
 
     def __check_frame(self, frame_rgb):

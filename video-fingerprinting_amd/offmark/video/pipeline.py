@@ -42,6 +42,13 @@ def pix_fmt_of(obj) -> str:
     return fmt
 
 
+def batch_size(batch_frames: int, item_shape, limit_bytes: int = 512 << 20) -> int:
+    """Frames per pipeline batch: the caller's ``batch_frames``, cut down so that one batch stays under ``limit_bytes``
+    (the pipeline holds ~9 batch-sized buffers, five of them page-locked: 64 frames of 4K would be 14 GB of pinned memory)."""
+    per = int(np.prod(item_shape))
+    return max(1, min(int(batch_frames), limit_bytes // max(per, 1)))
+
+
 def frame_shape(pix_fmt: str, height: int, width: int) -> tuple:
     """Per-frame array shape at the reader / writer boundary."""
     if pix_fmt == "rgb24":
