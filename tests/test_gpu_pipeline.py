@@ -313,3 +313,24 @@ def test_mark_and_detect_drivers_over_file_readers_and_writers(eng, fake_ffmpeg,
     video_extractor = Extractor(FileDecoder(out_file, pix_fmt=pix_fmt), DwtDctSvdDecoder(), degenerator)
     video_extractor.start()
     assert len(video_extractor.patterns) == n and all(np.array_equal(p, payload) for p in video_extractor.patterns)
+
+
+def test_4k_frames_run_in_byte_bounded_batches(eng):
+    """64 frames of 4K per batch would pin 14 GB of host memory; the pipeline cuts a batch to 512 MiB (21 frames of 4K rgb24).
+    25 frames -> batches of 21 + 4, bit-equal to one direct call."""
+    from offmark.video.embedder import Embedder
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark.video.frame_writer import ArrayFrameWriter
+    from offmark.video.pipeline import batch_size, frame_shape
+    h, w, n = 2160, 3840, 25
+    assert batch_size(64, frame_shape("rgb24", h, w)) == 21
+    rng = np.random.default_rng(12)
+    small = rng.integers(0, 256, (n, h // 8, w // 8, 3), dtype=np.uint8)
+    src = np.ascontiguousarray(np.repeat(np.repeat(small, 8, axis=1), 8, axis=2))       # blocky 4K frames, cheap to make
+    src[:, ::3, ::5] ^= 0x15                                                           # plus some texture
+    enc, _ = make_codec("dct", h, w)
+    want = enc.encode_frames_u8(cuda(src)).cpu().numpy()
+    wr = ArrayFrameWriter()
+    emb = Embedder(ArrayFrameReader(src), enc, wr)                                     # default batch_frames = 64
+    emb.start()
+    assert emb.frames_marked == n and np.array_equal(np.stack(wr.frames), want)
