@@ -1,6 +1,6 @@
 import sys, time, os
 sys.path.insert(0, 'video-fingerprinting_amd')
-import numpy as np, torch
+import numpy as np
 from offmark.video import pipeline as pl
 print('cores', len(os.sched_getaffinity(0)), 'copy threads', pl._COPY_THREADS)
 src = np.random.default_rng(0).integers(0, 256, (50, 1080, 1920, 3), dtype=np.uint8)

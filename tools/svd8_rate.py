@@ -1,5 +1,5 @@
 """Launch durations of the DwtDctSvd kernels, blk = 4 against blk = 8, detect / embed / embed+verify (300 x 1080p)."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "video-fingerprinting_amd"))
 import numpy as np, torch
