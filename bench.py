@@ -17,6 +17,8 @@ payloads over the ranks (RCCL; a no-op on one GPU) and take the cross-frame vote
                         (payload = segment(4b)||copy(4b)), a leak takes one copy per segment plus the
                         build-defined re-quantisation attack; the timed step is the batched DETECT of the
                         leak's frames, the all-gather of the payloads and the vote -> copy sequence.
+                        --codec dwtdctsvd runs it with the codec the reference's leak scripts construct
+                        (tests/detect_watermarks.py:207).
 
   python bench.py --gpus 1 --steps 100 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -24,13 +26,26 @@ payloads over the ranks (RCCL; a no-op on one GPU) and take the cross-frame vote
   python bench.py --gpus N ...      with N > 1 and no launcher (WORLD_SIZE unset): bench.py starts that same
                                     torch.distributed.run command itself as a child process, before anything
                                     touches the GPU, and relays rank 0's line and the exit code.
+  python bench.py --config 4 --emulate-world 8
+                                    ONE GPU rehearses rank 0 of an 8-rank job: it processes rank 0's shard only, but
+                                    "gathers" (a device copy standing in for the RCCL all-gather) and votes over ALL ranks'
+                                    payloads, and also times the whole job on this GPU, so the line's `emulation` object
+                                    carries a predicted 8-GPU speed-up: T(whole job, 1 GPU) / T(rank 0's step).  `value`
+                                    stays what this one GPU really processed.
 `collective.ranks` / `rccl_ranks` = what an all-reduce of ones returned: the ranks the collective library really joined.
+
+Small shards (a 48-frame segment is 0.2 ms of GPU work, less than the host needs to issue a step): `--group G` (default: auto)
+issues G steps per host iteration -- the G steps' kernels are replayed as ONE captured hipGraph, their payloads are gathered
+and downloaded once, and the host votes on all G steps' payloads in one vectorised call; every step still embeds, detects,
+reduces and votes on its own batch.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (config 2: the fused mark+verify kernel:
 it re-reads each frame, writes the marked frame and analyzes it).  Launch durations (`kernels`) come
 from HIP event pairs the library attaches to every kernel dispatch of the timed steps
 (hipExtLaunchKernelGGL start/stop events on the launch stream: the dispatch's own timestamps, no marker
-packets, no measurable cost).  `roofline.traffic` (PMC-measured HBM bytes per launch) is taken from
+packets).  `mark_order` times the same K steps with the fused mark kernel in both tile orders, interleaved in this
+process, next to the engine's own calibration and the workgroup -> XCD deal the hardware reported.
+`roofline.traffic` (PMC-measured HBM bytes per launch) is taken from
 profiles/ only when that profile was made from exactly the kernel sources that are running (hash stamp),
 else null.  `cpu_baseline` is the plain-C restatement of the reference algorithm (oracle/offmark_oracle.c,
 bit-identical to the NumPy oracle and the golden vectors; kind "port": OpenCV is not installed, so the
@@ -44,6 +59,7 @@ import os
 import subprocess
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "video-fingerprinting_amd"))
@@ -52,6 +68,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 PAYLOAD = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+GRAPH_BELOW_BYTES = 100 * 1080 * 1920 * 3      # shards under 100 frames of 1080p: capture the step(s) as a hipGraph
 
 
 def parse():
@@ -75,13 +92,23 @@ def parse():
                          "12 B/px of traffic) instead of the fused mark+verify kernel; same results bit for bit")
     ap.add_argument("--codec", choices=["dct", "dwtdctsvd"], default="dct",
                     help="dct = the BASELINE.json hot path (default); dwtdctsvd = the codec mark.py/detect.py construct")
+    ap.add_argument("--blk", type=int, default=4, choices=[4, 8], help="DwtDctSvd block size (--codec dwtdctsvd)")
+    ap.add_argument("--pixfmt", choices=["rgb24", "i420", "nv12"], default="rgb24",
+                    help="frame layout in HBM (config 2/3, DCT codec): interleaved rgb24 (the metric) or 4:2:0 planes")
+    ap.add_argument("--tile-order", choices=["auto", "xcd", "linear"], default="auto",
+                    help="tile order of the fused mark kernel: auto = the engine's per-device calibration (default)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one GPU rehearses rank 0 of an M-rank job (see module text); needs --gpus 1")
+    ap.add_argument("--group", type=int, default=0, help="steps issued per host iteration (0 = auto: 1 for shards of >= 100 "
+                                                         "1080p frames, else as many as make ~300 frames)")
+    ap.add_argument("--no-graph", action="store_true", help="never capture the step as a hipGraph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (a one-GPU box cannot run RCCL across ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not attach HIP events to the kernel launches (roofline becomes null)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the separate-detect side measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of the CPU baseline's main (C, all cores) sample")
     return ap.parse_args()
 
@@ -115,11 +142,14 @@ def usable_cores():
 
 
 def cpu_baseline(frames_u8, wm, alpha, budget_s):
-    """The oracle on the host cores, embed+detect on a bounded sample of the same workload.
+    """The oracle on the host cores, embed+detect on a bounded sample of the same workload (SURVEY 8d / BASELINE.md 3).
     value: the C restatement (oracle/offmark_oracle.c, bit-identical to the NumPy oracle), one OpenMP thread per
     frame on every core this process may use.  variants: BASELINE.md section 3's forms of the NumPy oracle --
-    A reference-shaped per-block Python loop on one core, B1 all-blocks-at-once NumPy on one core, B2 = B1 in one
-    worker process per core (oracle/cpu_baseline_worker.py; separate processes that never touch the GPU)."""
+      A   reference-shaped per-block Python loop on one core, ONE WHOLE frame (SURVEY asks for >= 10: that is ~105 s of one
+          core at 0.095 frames/s, beyond a bench line's budget -- the count is stated);
+      B1  all-blocks-at-once NumPy on one core, 100 frames if they fit ~25 s, else as many as do (count stated);
+      B2  B1 in one worker process per core, >= 100 frames in all (oracle/cpu_baseline_worker.py; separate processes that
+          never touch the GPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     import offmark_oracle as orc
@@ -137,35 +167,43 @@ def cpu_baseline(frames_u8, wm, alpha, budget_s):
             break
     el = time.perf_counter() - t0
     variants = {}
+    small = H * W < 1920 * 1080                       # shortened test runs: keep the variants proportionate
     try:
         # B1: vectorised NumPy, one core
         enc = orc.DctEncoderOracle(alpha=alpha)
         enc.read_wm(wm)
-        t1, k = time.perf_counter(), 3
-        for i in range(k):
-            orc.check_frame(orc.mark_frame(frames_u8[i], enc), orc.DctDecoderOracle(alpha=alpha))
-        variants["B1_numpy_vectorised"] = dict(value=round(k / (time.perf_counter() - t1), 2), unit="frames/s", cores=1, frames=k)
-        # A: reference-shaped per-block Python loop, one core, on a quarter-frame crop scaled by its block count
-        crop = np.ascontiguousarray(frames_u8[0][: H // 16 * 8, : W // 16 * 8])
-        ch, cw = crop.shape[:2]
+        t1, k, want, limit = time.perf_counter(), 0, (10 if small else 100), (5.0 if small else 25.0)
+        b1_ok = True
+        while k < want:
+            b = orc.check_frame(orc.mark_frame(frames_u8[k % n], enc), orc.DctDecoderOracle(alpha=alpha))
+            b1_ok &= bool(np.array_equal(orc.deshuffle(b, PAYLOAD.size, 0), PAYLOAD))
+            k += 1
+            spent = time.perf_counter() - t1
+            if k >= 3 and spent * (k + 1) / k > limit:
+                break
+        variants["B1_numpy_vectorised"] = dict(value=round(k / (time.perf_counter() - t1), 2), unit="frames/s", cores=1, frames=k,
+                                               payload_ok=b1_ok, note=None if k >= want else f"{want} frames do not fit {limit:.0f} s on one core")
+        # A: reference-shaped per-block Python loop, one core, one whole frame
+        fa = frames_u8[0]
         encl = orc.DctEncoderOracle(alpha=alpha, form="loop")
-        encl.read_wm(orc.shuffle_generate(PAYLOAD, (1, ch * cw // 64), 0))
+        encl.read_wm(wm)
         t2 = time.perf_counter()
-        orc.check_frame(orc.mark_frame(crop, encl), orc.DctDecoderOracle(alpha=alpha, form="loop"))
-        ta = (time.perf_counter() - t2) * ((H // 8) * (W // 8)) / ((ch // 8) * (cw // 8))
-        variants["A_reference_shaped_loop"] = dict(value=round(1.0 / ta, 3), unit="frames/s", cores=1,
-                                                   frames=round((ch * cw) / (H * W), 3),
-                                                   note=f"timed on a {cw}x{ch} crop, scaled by the block count")
+        ba = orc.check_frame(orc.mark_frame(fa, encl), orc.DctDecoderOracle(alpha=alpha, form="loop"))
+        ta = time.perf_counter() - t2
+        variants["A_reference_shaped_loop"] = dict(value=round(1.0 / ta, 4), unit="frames/s", cores=1, frames=1,
+                                                   payload_ok=bool(np.array_equal(orc.deshuffle(ba, PAYLOAD.size, 0), PAYLOAD)),
+                                                   note=f"one whole {W}x{H} frame, {ta:.1f} s (SURVEY 8d asks for >= 10 frames: "
+                                                        f"{10 * ta:.0f} s of one core, beyond this line's budget)")
     except Exception as exc:
         variants["error_A_B1"] = repr(exc)
-    # B2: B1 fanned out, one worker process per core
+    # B2: B1 fanned out, one worker process per core, >= 100 frames in all
     try:
-        per = 2
+        per = max(2, -(-(10 if small else 100) // threads))
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline_worker.py"), str(H), str(W),
                                    str(per), str(3000 + i), str(alpha)], stdout=subprocess.PIPE, text=True, env=env)
                  for i in range(threads)]
-        spans = [json.loads(p.communicate(timeout=300)[0].strip().splitlines()[-1]) for p in procs]
+        spans = [json.loads(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in procs]
         wall = max(s["t1"] for s in spans) - min(s["t0"] for s in spans)
         variants["B2_numpy_vectorised_all_cores"] = dict(value=round(threads * per / wall, 2), unit="frames/s", cores=threads,
                                                          frames=threads * per, payload_ok=all(s["ok"] for s in spans))
@@ -179,13 +217,14 @@ def cpu_baseline(frames_u8, wm, alpha, budget_s):
                 variants=variants)
 
 
-def attack_suite(torch, eng, clean, per_seg, payloads, chosen, fp, vote_segments, deg, N, alpha, H, W):
+def attack_suite(torch, detect, clean, per_seg, payloads, chosen, fp, vote_segments, deg, n_bits, H, W, codec):
     """BASELINE.json configs[4]: the leak's frames under the build-defined attacks of SURVEY 8d (none exist upstream: the
     reference's only lossy leg is a JPEG, tests/test.py:99, and its HLS re-encode).  `clean`: marked frames [S * per_seg, H, W, 3]
-    on the device.  Per attack: payload bit error rate over the frames, frames decoded exactly, segments whose Counter vote is
-    right, and whether the leak's copy sequence comes out.  Reported as measured: cropping moves the 8x8 grid and is EXPECTED to
-    defeat a block-DCT QIM scheme (so is a strong re-quantisation such as JPEG quality 75); a mild rescale may or may not survive
-    depending on the content; only "none" and "noise" are parity-gated (tests)."""
+    on the device; `detect(frames) -> counts [n, L]` is the codec's read-out.  Per attack: payload bit error rate over the frames,
+    frames decoded exactly, segments whose Counter vote is right, and whether the leak's copy sequence comes out.  Reported as
+    measured: cropping moves the 8x8 grid and is EXPECTED to defeat a block-transform QIM scheme (so is a strong re-quantisation
+    such as JPEG quality 75); a mild rescale may or may not survive depending on the content; only "none" and "noise" are
+    parity-gated (tests)."""
     import io
     S = len(payloads)
     seg = np.repeat(np.arange(S), per_seg)
@@ -221,16 +260,53 @@ def attack_suite(torch, eng, clean, per_seg, payloads, chosen, fp, vote_segments
     out = {}
     for name, fn in attacks.items():
         try:
-            counts, _ = eng.detect(fn(clean), PAYLOAD.size, alpha=alpha)
-            got = deg.degenerate_counts(counts.cpu().numpy(), N)
+            counts = detect(fn(clean))
+            got = deg.degenerate_counts(counts.cpu().numpy(), n_bits)
             votes = vote_segments(got, seg)
             seg_ok = sum(int(v[0] is not None and np.array_equal(v[0], payloads[s])) for s, v in votes.items())
             out[name] = dict(payload_ber=round(float((got != want).mean()), 4), frames_exact=round(float((got == want).all(axis=1).mean()), 4),
                              segments_ok=f"{seg_ok}/{S}", copies_recovered=fp.identify_copies({s + 1: v for s, v in votes.items()}) == chosen)
         except Exception as exc:                                   # never lose the line over a side report
             out[name] = dict(error=repr(exc))
-    out["note"] = (f"{per_seg} frames per segment, DCT codec; attacks are build-defined tensor ops between embed and detect (Pillow for the JPEGs); "
-                   "a crop moves the 8x8 grid and is expected to fail for this scheme; the others are reported as measured")
+    out["note"] = (f"{per_seg} frames per segment, {codec} codec; attacks are build-defined tensor ops between embed and detect (Pillow for the "
+                   "JPEGs); a crop moves the block grid and is expected to fail for this scheme; the others are reported as measured")
+    return out
+
+
+def plugin_yuv32f_rates(H, W, alpha, frame_u8):
+    """The LITERAL plugin boundary an unmodified reference Embedder / Extractor would call once per frame
+    (src/offmark/video/embedder.py:35, extractor.py:32; tests/test.py:91-118): encode(yuv) / decode(yuv) on ONE host float32
+    YUV frame -- upload 12 B/px, kernels, download.  Frames/s per call, both codecs; not tuned (a single-frame API), reported
+    so that path has a number."""
+    from offmark.embed.dct_encoder import DctEncoder
+    from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder
+    from offmark.extract.dct_decoder import DctDecoder
+    from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.generator.shuffler import Shuffler
+    from offmark.video.color import bgr2yuv
+    yuv0 = bgr2yuv(frame_u8.astype(np.float32))
+    deg = DeShuffler(key=0).set_shape(PAYLOAD.shape)
+    out = {}
+    for name, enc, dec in (("dct", DctEncoder(alpha=alpha), DctDecoder(alpha=alpha)),
+                           ("dwtdctsvd", DwtDctSvdEncoder(), DwtDctSvdDecoder())):
+        enc.read_wm(Shuffler(key=0).generate_wm(PAYLOAD, enc.wm_capacity((H, W, 3))))
+        marked = enc.encode(yuv0.copy())
+        bits = dec.decode(marked)                             # warm: allocations, code objects
+        k = 8
+        t0 = time.perf_counter()
+        for _ in range(k):
+            marked = enc.encode(yuv0.copy())
+        t1 = time.perf_counter()
+        for _ in range(k):
+            bits = dec.decode(marked)
+        t2 = time.perf_counter()
+        out[name] = dict(encode_fps=round(k / (t1 - t0), 1), decode_fps=round(k / (t2 - t1), 1),
+                         encode_decode_fps=round(k / (t2 - t0), 1), calls=k,
+                         payload_ok=bool(np.array_equal(deg.degenerate(bits), PAYLOAD)))
+    out["note"] = (f"DctEncoder.encode(yuv) / DctDecoder.decode(yuv) and the DwtDctSvd pair on one host float32 {W}x{H} YUV frame per call "
+                   "(pageable ndarray up, kernels, channel(s) down; includes the caller's yuv.copy()): the path an unmodified reference "
+                   "Embedder takes (video/embedder.py:35).  The batched u8 path is the product's fast path")
     return out
 
 
@@ -268,15 +344,18 @@ def launch_ranks(a):
 
 def main():
     a = parse()
+    if a.emulate_world and a.gpus != 1:
+        raise SystemExit("--emulate-world needs --gpus 1 (it rehearses rank 0 of an M-rank job on ONE GPU)")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)
     import torch
     import torch.distributed as dist
     from offmark import _hip
+    from offmark import engine as engine_mod
     from offmark import fingerprint as fp
     from offmark.degenerator.de_shuffler import DeShuffler
     from offmark.dist.vote import gather_payloads, init_from_env, shard_range, vote_segments
-    from offmark.engine import DctEngine, default_chunk_frames
+    from offmark.engine import DctEngine, balanced_chunk, default_chunk_frames
     from offmark.generator.shuffler import Shuffler
     from offmark.synthetic import synthetic_frames
 
@@ -286,6 +365,7 @@ def main():
     grouped = world > 1 or a.rehearse_collectives          # a process group exists: run the collectives
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    emu = a.emulate_world if a.emulate_world > 1 else 0
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -297,86 +377,19 @@ def main():
         dist.all_reduce(one)
         ranks_seen = int(one.item())
 
-    # ---- workload ------------------------------------------------------------------------------------
     cfg = a.config
     H = a.height or (2160 if cfg == 3 else 1080)
     W = a.width or (3840 if cfg == 3 else 1920)
     N = H * W // 64
+    L = int(PAYLOAD.size)
+    planar = a.pixfmt != "rgb24"
+    if planar and (cfg not in (2, 3) or a.codec != "dct" or a.separate_detect or H % 8 or W % 8):
+        raise SystemExit("--pixfmt i420/nv12: configs 2/3, DCT codec, fused verify, H and W multiples of 8")
+    # bits in the decoder's vector: what the degenerator's means divide by (dwt_dct_svd_decoder.py:14 for blk = 8)
+    n_bits = DctEngine.svd_bits_per_frame(H, W, a.blk) if a.codec == "dwtdctsvd" else N
     deg = DeShuffler(key=0).set_shape(PAYLOAD.shape)
-    S, F, C = 8, 48, 3                                       # configs 4/5: segments, frames per segment, copies
-    chosen = None
-    if cfg in (2, 3):
-        scaling, equal = "weak", True
-        n = a.frames or (1000 if cfg == 3 else 300)
-        frames = synthetic_frames(n, H, W, seed=2000 + rank, device=dev)
-        wm_table = Shuffler(key=0).generate_wm(PAYLOAD, (1, N)).astype(np.uint8)
-        rows_local = None
-        seg_global = np.repeat(np.arange(world), n)          # one "segment" per rank
-        first = rank * n
-        expected = {r: PAYLOAD for r in range(world)}
-        total_frames = world * n
-        mode = "embed_detect"
-    else:
-        scaling = "strong"                                   # the 8-segment job is split over the ranks
-        if a.frames:
-            F = a.frames
-        s0, s1 = shard_range(S, rank, world)
-        n, first = (s1 - s0) * F, s0 * F
-        equal = S % world == 0
-        seg_global = np.repeat(np.arange(S), F)
-        total_frames = S * F
-        src = synthetic_frames(max(n, 1), H, W, seed=4000 + rank, device=dev)[:n]
-        if cfg == 4:
-            # segment s carries format(s % 256, '08b'); numbering starts at 1 because segment 0's all-zero payload
-            # cannot be decoded by the reference's mid-range threshold (de_shuffler.py:20-21)
-            payloads = np.stack([fp.payload_for_segment(s + 1) for s in range(S)])
-            wm_table = np.stack([Shuffler(key=0).generate_wm(p, (1, N))[0] for p in payloads]).astype(np.uint8)
-            rows_local = np.repeat(np.arange(s0, s1), F).astype(np.int32)
-            expected = {s: payloads[s] for s in range(S)}
-            frames = src
-            mode = "embed_detect"
-        else:
-            table = np.stack([Shuffler(key=0).generate_wm(fp.payload_for_segment(s + 1, c), (1, N))[0]
-                              for s in range(S) for c in range(C)]).astype(np.uint8)
-            chosen = fp.select_copies("01201201", S, C)
-            rows = np.array([(s * C + chosen[s]) for s in range(s0, s1) for _ in range(F)], dtype=np.int32)
-            setup = DctEngine(device=dev)
-            leak = setup.embed(src, table, alpha=a.alpha, wm_row=rows) if n else src
-            g = torch.Generator(device=dev).manual_seed(7 + rank)    # build-defined attack (i): N(0, 2) + round/clip
-            frames = (leak.float() + 2.0 * torch.randn(leak.shape, device=dev, generator=g)).round().clamp(0, 255).to(torch.uint8)
-            # a few clean frames of every local segment for the attack suite reported next to the line (not timed)
-            keep = min(F, 8)
-            leak_sample = leak.view(s1 - s0, F, H, W, 3)[:, :keep].reshape(-1, H, W, 3).clone() if n else None
-            del leak, setup
-            wm_table, rows_local = None, None
-            expected = {s: fp.payload_for_segment(s + 1, chosen[s]) for s in range(S)}
-            mode = "detect"
-    out = torch.empty_like(frames) if mode == "embed_detect" else None
-    wm_dev = torch.from_numpy(wm_table).to(dev) if wm_table is not None else None
-    rows_dev = torch.from_numpy(rows_local).to(dev) if rows_local is not None else None
-    chunk = a.chunk or default_chunk_frames(H, W)
-    n_chunks = max(1, (n + chunk - 1) // chunk)
-    timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
-    DOMINANT = ("analyze" if mode == "detect" else "mark" if a.separate_detect else "mark_fused") if a.codec == "dct" else "svd"
-    # event pairs on the DOMINANT kernel's launches only while `value` is timed (a pair on every launch of a step costs ~1.3 %
-    # of the step: measured 267.5 k against 271.0 k frames/s, interleaved); the other kernels' durations come from a short pass
-    # of their own after the timed region (`kernels`)
-    timing = None if a.no_kernel_events else _hip.Timing(2 * n_chunks * timed_steps + 16, 1 << _hip.TIMING_KINDS.index(DOMINANT))
-    opts_plain = _hip.Opts(flags, 0, None)
-    opts_timed = timing.opts(flags) if timing else opts_plain
-    lanes = [dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain), out=out, stream=torch.cuda.current_stream())]
-    if a.streams == 2:
-        lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain),
-                          out=torch.empty_like(frames) if out is not None else None, stream=torch.cuda.Stream()))
-
     perm_dev = torch.as_tensor(deg.payload_idx, dtype=torch.int32).to(dev)
-    host = [torch.empty((total_frames, PAYLOAD.size), dtype=torch.uint8).pin_memory() for _ in range(2)]
-    ready = [torch.cuda.Event() for _ in range(2)]
-
-    side = torch.cuda.Stream()                    # all-gather + download: off the compute stream, so a slow
-    handoff = [torch.cuda.Event() for _ in range(2)]   # peer never stalls this rank's next step
-
-    host_s = {"enqueue": 0.0, "vote": 0.0}     # host-side seconds spent issuing work / voting (not waiting)
+    S, F, C = 8, a.frames or 48, 3                           # configs 4/5: segments, frames per segment, copies
 
     def barrier():
         if a.backend == "nccl":
@@ -384,159 +397,435 @@ def main():
         else:
             dist.barrier()
 
-    def hot_path(e, lane_out):
-        """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames."""
-        if n == 0:
-            return torch.empty((0, PAYLOAD.size), dtype=torch.uint8, device=dev)
-        if mode == "detect":
-            counts, _ = e.detect(frames, PAYLOAD.size, alpha=a.alpha)
-        elif a.codec == "dct":
-            _, counts, _ = e.embed_detect(frames, wm_dev, L=PAYLOAD.size, alpha=a.alpha, wm_row=rows_dev, out=lane_out)
+    # ---- workload: one rank's share of a BASELINE config --------------------------------------------------------
+    def make_job(shard_rank, shard_world, share=None):
+        """The frames, watermarks and bookkeeping of rank `shard_rank` of `shard_world` ranks.  `share`: a job of the WHOLE
+        workload (one rank) whose tensors this shard may slice instead of generating its own (emulation: both live on this GPU)."""
+        j = SimpleNamespace(chosen=None, leak_sample=None, keep=0, rows_dev=None, wm_dev=None, planes=None)
+        if cfg in (2, 3):
+            j.scaling, j.equal = "weak", True
+            j.n = a.frames or (1000 if cfg == 3 else 300)
+            j.frames = share.frames if share is not None else synthetic_frames(j.n, H, W, seed=2000 + shard_rank, device=dev)
+            j.wm_table = Shuffler(key=0).generate_wm(PAYLOAD, (1, N)).astype(np.uint8)
+            j.seg_global = np.repeat(np.arange(shard_world), j.n)          # one "segment" per rank
+            j.first = shard_rank * j.n
+            j.expected = {r: PAYLOAD for r in range(shard_world)}
+            j.total_frames = shard_world * j.n
+            j.mode = "embed_detect"
+            j.wm_dev = torch.from_numpy(j.wm_table).to(dev)
+            if planar:
+                j.planes = share.planes if share is not None else DctEngine(device=dev).rgb_to_yuv420(j.frames, a.pixfmt)
         else:
-            _, counts, _ = e.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, wm_row=rows_dev, out=lane_out)
-        return e.payloads(counts, N, perm_dev)                             # [n, L] uint8, on device
-
-    def enqueue(k):
-        """GPU half of step k; then, on a side stream, the all-gather of the payloads and their download into
-        pinned memory."""
-        t_in = time.perf_counter()
-        lane = lanes[k % len(lanes)]
-        with torch.cuda.stream(lane["stream"]):
-            mine = hot_path(lane["eng"], lane["out"])
-            handoff[k & 1].record()
-        with torch.cuda.stream(side):
-            side.wait_event(handoff[k & 1])
-            mine.record_stream(side)
-            if a.backend == "gloo" and grouped:                        # rehearsal: gloo gathers host tensors
-                everyone = gather_payloads(mine.cpu(), equal_shards=equal, force=grouped)
+            j.scaling = "strong"                                 # the 8-segment job is split over the ranks
+            s0, s1 = shard_range(S, shard_rank, shard_world)
+            j.n, j.first = (s1 - s0) * F, s0 * F
+            j.equal = S % shard_world == 0
+            j.seg_global = np.repeat(np.arange(S), F)
+            j.total_frames = S * F
+            if share is not None:
+                src = share.src[j.first:j.first + j.n]
             else:
-                everyone = gather_payloads(mine, equal_shards=equal, force=grouped)      # RCCL all-gather (N > 1)
-            host[k & 1].copy_(everyone, non_blocking=True)
-            ready[k & 1].record()
-        host_s["enqueue"] += time.perf_counter() - t_in
-        return mine
+                # every rank's frames come from ONE generator stream (seed 4000), so that a shard is the same frames whether
+                # it is generated alone or sliced out of the whole job
+                src = synthetic_frames(S * F, H, W, seed=4000, device=dev)[j.first:j.first + j.n].clone() if shard_world > 1 \
+                    else synthetic_frames(S * F, H, W, seed=4000, device=dev)
+            j.src = src
+            if cfg == 4:
+                # segment s carries format(s % 256, '08b'); numbering starts at 1 because segment 0's all-zero payload
+                # cannot be decoded by the reference's mid-range threshold (de_shuffler.py:20-21)
+                payloads = np.stack([fp.payload_for_segment(s + 1) for s in range(S)])
+                j.wm_table = np.stack([Shuffler(key=0).generate_wm(p, (1, N))[0] for p in payloads]).astype(np.uint8)
+                j.rows_dev = torch.from_numpy(np.repeat(np.arange(s0, s1), F).astype(np.int32)).to(dev)
+                j.wm_dev = torch.from_numpy(j.wm_table).to(dev)
+                j.expected = {s: payloads[s] for s in range(S)}
+                j.frames = src
+                j.mode = "embed_detect"
+            else:
+                j.chosen = fp.select_copies("01201201", S, C)
+                j.expected = {s: fp.payload_for_segment(s + 1, j.chosen[s]) for s in range(S)}
+                j.mode = "detect"
+                if share is not None:
+                    j.frames = share.frames[j.first:j.first + j.n]
+                else:
+                    table = np.stack([Shuffler(key=0).generate_wm(fp.payload_for_segment(s + 1, c), (1, N))[0]
+                                      for s in range(S) for c in range(C)]).astype(np.uint8)
+                    rows = np.array([(s * C + j.chosen[s]) for s in range(s0, s1) for _ in range(F)], dtype=np.int32)
+                    setup = DctEngine(device=dev)
+                    if j.n == 0:
+                        leak = src
+                    elif a.codec == "dct":
+                        leak = setup.embed(src, table, alpha=a.alpha, wm_row=rows)
+                    else:
+                        leak = setup.svd_embed(src, table, scale=15, wm_row=rows, blk=a.blk)
+                    g = torch.Generator(device=dev).manual_seed(7 + shard_rank)    # build-defined attack (i): N(0, 2) + round/clip
+                    j.frames = (leak.float() + 2.0 * torch.randn(leak.shape, device=dev, generator=g)).round().clamp(0, 255).to(torch.uint8) \
+                        if j.n else leak
+                    # a few clean frames of every local segment for the attack suite reported next to the line (not timed)
+                    j.keep = min(F, 8)
+                    j.leak_sample = leak.view(s1 - s0, F, H, W, 3)[:, :j.keep].reshape(-1, H, W, 3).clone() if j.n else None
+                    del leak, setup
+        j.shard_world, j.shard_rank = shard_world, shard_rank
+        # the payload every frame of the WHOLE job should decode to (what the other ranks contribute in an emulation)
+        j.expected_rows = np.stack([j.expected[s] for s in j.seg_global]).astype(np.uint8)
+        return j
 
-    def finish(k):
-        """Host half of step k: the reference's cross-frame Counter vote, once its payloads have landed.
-        It runs while the GPU is already working on step k+1 (double-buffered)."""
-        ready[k & 1].synchronize()
-        t_in = time.perf_counter()
-        v = vote_segments(host[k & 1].numpy(), seg_global)
-        host_s["vote"] += time.perf_counter() - t_in
-        return v
+    if emu:
+        if cfg in (4, 5) and S % emu:
+            raise SystemExit(f"--emulate-world {emu}: the {S} segments must split evenly over the emulated ranks")
+        job_full = make_job(0, 1)
+        job = make_job(0, emu, share=job_full)
+    else:
+        job_full = None
+        job = make_job(rank, world)
+    n = job.n
+    mode = job.mode
+    DOMINANT = ("analyze" if mode == "detect" else "mark" if a.separate_detect else "mark_fused") if a.codec == "dct" else "svd"
+    if planar:
+        DOMINANT = "planar_mark"
+    opts_plain = _hip.Opts(flags, 0, None)
 
-    def run(steps):
-        mine = None
-        for k in range(steps):
-            mine = enqueue(k)
-            if k:
-                finish(k - 1)
-        return finish(steps - 1), mine
+    # ---- the step over one job ---------------------------------------------------------------------------------
+    class Runner:
+        """Issues steps of one job: lanes (engine + output buffer + stream), the side stream with the all-gather and the
+        download, the host-side vote; G steps per host iteration, optionally as one captured hipGraph."""
 
-    def fence():
-        torch.cuda.synchronize()
-        if grouped:
-            barrier()
-        torch.cuda.synchronize()
+        def __init__(self, j, n_lanes=1, group=1, graph=False, emulate=False):
+            self.j, self.G, self.use_graph, self.emulate = j, max(1, group), graph, emulate
+            self.chunk = a.chunk or default_chunk_frames(H, W)
+            self.cf = balanced_chunk(max(j.n, 1), self.chunk)
+            self.n_chunks = max(1, -(-j.n // self.cf))
+            self.lanes = []
+            for i in range(n_lanes):
+                self.add_lane(torch.cuda.current_stream() if i == 0 else torch.cuda.Stream())
+            self.side = torch.cuda.Stream()            # all-gather + download: off the compute stream, so a slow peer never
+            self.handoff = [torch.cuda.Event() for _ in range(2)]      # stalls this rank's next step
+            self.ready = [torch.cuda.Event() for _ in range(2)]
+            rows = j.total_frames * self.G
+            self.host = [torch.empty((rows, L), dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.host_s = {"enqueue": 0.0, "vote": 0.0}        # host-side seconds spent issuing work / voting (not waiting)
+            self.S_ids = int(j.seg_global.max()) + 1 if j.total_frames else 1
+            self._ids = {}
+            if emulate:        # the gathered buffer of an M-rank job, rank-major [M, G, n, L]: the other ranks' parts are pre-filled
+                ew = j.shard_world
+                per_rank = torch.from_numpy(j.expected_rows).to(dev).view(ew, 1, j.n, L).expand(ew, self.G, j.n, L).contiguous()
+                self.everyone = [per_rank.clone() for _ in range(2)]
 
-    def timed(steps):
-        fence()
-        host_s.update(enqueue=0.0, vote=0.0)
-        t0 = time.perf_counter()
-        votes, mine = run(steps)
-        fence()
-        el = time.perf_counter() - t0
-        if grouped:
-            t = torch.tensor([el], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, votes, mine
+        def add_lane(self, stream):
+            j = self.j
+            src = j.planes if planar else j.frames
+            lane = SimpleNamespace(eng=DctEngine(device=dev, chunk_frames=self.chunk, opts=opts_plain, tile_order=a.tile_order),
+                                   out=torch.empty_like(src) if j.mode == "embed_detect" else None, stream=stream,
+                                   pay=torch.empty((self.G, max(j.n, 0), L), dtype=torch.uint8, device=dev), graph=None)
+            self.lanes.append(lane)
+            return lane
 
-    # one-time setup, not a workload step: allocate the scratch for the chunk size in use and let the runtime load
-    # the code objects (one full-size pass, so that profiles only ever see full-size launches); even --warmup 0 then
-    # times steady-state steps
-    for lane in lanes:
-        if n:
-            lane["eng"].workspace(H, W, lane["eng"]._chunk(n, H, W))
-        with torch.cuda.stream(lane["stream"]):
-            p1 = hot_path(lane["eng"], lane["out"])
-    torch.cuda.synchronize()
+        def set_opts(self, o):
+            for lane in self.lanes:
+                lane.eng.opts = o
+
+        def set_order(self, order):
+            for lane in self.lanes:
+                lane.eng._order_mode = order
+            self.drop_graphs()
+
+        def drop_graphs(self):
+            for lane in self.lanes:
+                lane.graph = None
+
+        def hot_path(self, lane, slot=0):
+            """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames -> lane.pay[slot]."""
+            j, e = self.j, lane.eng
+            if j.n == 0:
+                return
+            if j.mode == "detect":
+                if a.codec == "dct":
+                    counts, _ = e.detect(j.frames, L, alpha=a.alpha)
+                else:
+                    counts, _ = e.svd_detect(j.frames, L, scale=15, blk=a.blk)
+            elif planar:
+                _, counts, _ = e.embed_detect_yuv420(j.planes, H, W, j.wm_dev, L, alpha=a.alpha, out=lane.out, layout=a.pixfmt)
+            elif a.codec == "dct":
+                _, counts, _ = e.embed_detect(j.frames, j.wm_dev, L=L, alpha=a.alpha, wm_row=j.rows_dev, out=lane.out)
+            else:
+                _, counts, _ = e.svd_embed_detect(j.frames, j.wm_dev, L=L, scale=15, wm_row=j.rows_dev, out=lane.out, blk=a.blk)
+            e.payloads(counts, n_bits, perm_dev, out=lane.pay[slot])         # [n, L] uint8, on device
+
+        def prepare(self):
+            """One-time set-up, not a workload step: allocate the scratch for the chunk size in use, let the runtime load the code
+            objects and the engine calibrate its tile order (one full-size pass, so that profiles only ever see full-size launches);
+            capture the G-step graph when asked.  Even --warmup 0 then times steady-state steps."""
+            j = self.j
+            for lane in self.lanes:
+                if j.n:
+                    lane.eng.workspace(H, W, lane.eng._chunk(j.n, H, W))
+                with torch.cuda.stream(lane.stream):
+                    self.hot_path(lane)
+            torch.cuda.synchronize()
+
+        def capture(self, lane):
+            """G steps of this lane as ONE hipGraph (C-ABI calls only enqueue work, so they capture)."""
+            cs = torch.cuda.Stream()
+            with torch.cuda.stream(cs):
+                for g_ in range(self.G):
+                    self.hot_path(lane, g_)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cs):
+                    for g_ in range(self.G):
+                        self.hot_path(lane, g_)
+            torch.cuda.synchronize()
+            lane.graph = graph
+
+        def ids_for(self, size):
+            """segment ids of the gathered rows of a group of `size` steps, rank-major [ranks, size, n_per_rank]: step g's segment s
+            votes under id g * S + s."""
+            if size not in self._ids:
+                j = self.j
+                if size == 1:
+                    self._ids[size] = j.seg_global
+                else:
+                    ranks = j.total_frames // max(j.n, 1)
+                    seg = j.seg_global.reshape(ranks, 1, j.n)
+                    self._ids[size] = (np.arange(size)[None, :, None] * self.S_ids + seg).reshape(-1)
+            return self._ids[size]
+
+        def enqueue(self, g, size):
+            """GPU half of group g (`size` steps); then, on a side stream, the all-gather of the payloads and their download into
+            pinned memory."""
+            t_in = time.perf_counter()
+            j = self.j
+            lane = self.lanes[g % len(self.lanes)]
+            timed_launches = lane.eng.opts is not None and lane.eng.opts.timing
+            with torch.cuda.stream(lane.stream):
+                if self.use_graph and size == self.G and not timed_launches and j.n:
+                    if lane.graph is None:
+                        self.capture(lane)
+                    lane.graph.replay()
+                else:
+                    for g_ in range(size):
+                        self.hot_path(lane, g_)
+                self.handoff[g & 1].record()
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.handoff[g & 1])
+                mine = lane.pay[:size].reshape(size * j.n, L)
+                mine.record_stream(self.side)
+                if self.emulate:                                               # a device copy where the RCCL all-gather would be
+                    buf = self.everyone[g & 1]
+                    buf[0, :size].copy_(lane.pay[:size])
+                    everyone = buf[:, :size].reshape(-1, L)
+                elif a.backend == "gloo" and grouped:                          # rehearsal: gloo gathers host tensors
+                    everyone = gather_payloads(mine.cpu(), equal_shards=j.equal, force=grouped)
+                else:
+                    everyone = gather_payloads(mine, equal_shards=j.equal, force=grouped)      # RCCL all-gather (N > 1)
+                self.host[g & 1][:everyone.shape[0]].copy_(everyone, non_blocking=True)
+                self.ready[g & 1].record()
+            self.host_s["enqueue"] += time.perf_counter() - t_in
+            return everyone.shape[0]
+
+        def finish(self, g, size, rows):
+            """Host half of group g: the reference's cross-frame Counter vote, once its payloads have landed.
+            It runs while the GPU is already working on group g+1 (double-buffered)."""
+            self.ready[g & 1].synchronize()
+            t_in = time.perf_counter()
+            v = vote_segments(self.host[g & 1][:rows].numpy(), self.ids_for(size))
+            self.host_s["vote"] += time.perf_counter() - t_in
+            return v
+
+        def plan(self, steps):
+            full, rest = divmod(steps, self.G)
+            return [self.G] * full + ([rest] if rest else [])
+
+        def run(self, steps):
+            """`steps` steps in groups; returns (the last group's votes, that group's size)."""
+            sizes = self.plan(steps)
+            prev = None
+            for g, size in enumerate(sizes):
+                rows = self.enqueue(g, size)
+                if prev is not None:
+                    self.finish(*prev)
+                prev = (g, size, rows)
+            return self.finish(*prev), prev[1]
+
+        def fence(self):
+            torch.cuda.synchronize()
+            if grouped:
+                barrier()
+            torch.cuda.synchronize()
+
+        def timed(self, steps):
+            self.fence()
+            self.host_s.update(enqueue=0.0, vote=0.0)
+            t0 = time.perf_counter()
+            votes, size = self.run(steps)
+            self.fence()
+            el = time.perf_counter() - t0
+            if grouped:
+                t = torch.tensor([el], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el, votes, size
+
+        def votes_ok(self, votes, size):
+            """every step of the (last) group: every segment's vote equals its payload (config 5: and the leak's copy sequence)."""
+            j = self.j
+            ok = len(votes) == size * len(j.expected)
+            for g_ in range(size):
+                vg = {s: votes.get(g_ * self.S_ids + s if size > 1 else s) for s in j.expected}
+                ok = ok and all(v is not None and v[0] is not None and np.array_equal(v[0], j.expected[s]) for s, v in vg.items())
+                if ok and cfg == 5:
+                    ok = fp.identify_copies({s + 1: v for s, v in vg.items()}) == j.chosen
+            return ok
+
+    # steps per host iteration and graph capture: only shards too small to hide the host behind (module text)
+    shard_bytes = n * H * W * 3
+    small_shard = 0 < shard_bytes < GRAPH_BELOW_BYTES
+    if a.group:
+        G = a.group
+    elif small_shard and job.equal:
+        G = max(1, min(16, -(-300 * 1080 * 1920 * 3 // max(shard_bytes, 1))))
+        while G > 1 and a.steps % G:            # a divisor of the step count: every group of the timed region is a full one
+            G -= 1
+    else:
+        G = 1
+    if not job.equal:
+        G = 1
+    use_graph = small_shard and not a.no_graph and a.streams == 1
+    runner = Runner(job, n_lanes=a.streams, group=G, graph=use_graph, emulate=bool(emu))
+    lanes = runner.lanes
+    n_chunks = runner.n_chunks
+    chunk = runner.cf
+    timed_steps = min(a.steps, 2000)                        # event pairs are pre-created; bound their number
+    # event pairs on the DOMINANT kernel's launches only while `value` is timed (a pair on every launch of a step costs ~1.3 %
+    # of the step: measured 267.5 k against 271.0 k frames/s, interleaved); the other kernels' durations come from a short pass
+    # of their own after the timed region (`kernels`).  A graphed step carries no events (they ride on the dispatch, a graph
+    # node has none): its dominant kernel is measured in that pass too.
+    events_in_timed_region = not a.no_kernel_events and not use_graph
+    timing = _hip.Timing(2 * n_chunks * timed_steps + 16, 1 << _hip.TIMING_KINDS.index(DOMINANT)) if events_in_timed_region else None
+    opts_timed = timing.opts(flags) if timing else opts_plain
+
+    runner.prepare()
     if grouped:                                     # first collective on the side stream: RCCL sets its channels up here
-        with torch.cuda.stream(side):
-            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=equal, force=grouped)
+        with torch.cuda.stream(runner.side):
+            p1 = lanes[0].pay[:1].reshape(-1, L)
+            gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=job.equal, force=grouped)
         torch.cuda.synchronize()
-    for lane in lanes:
-        lane["eng"].opts = opts_timed                       # every kernel of the timed steps carries its own event pair ...
+    runner.set_opts(opts_timed)                             # every dominant-kernel launch of the timed steps carries its own event pair ...
     if a.warmup:
-        run(a.warmup)                                       # ... and so do the warm-up steps: they are the timed steps' twins
+        runner.run(a.warmup)                                # ... and so do the warm-up steps: they are the timed steps' twins
         if timing:
             torch.cuda.synchronize()
             timing.collect()                                # rewind the event pool: the durations reported are the timed region's
-    elapsed, votes, mine = timed(a.steps)
-    host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in host_s.items()}
-    for lane in lanes:
-        lane["eng"].opts = opts_plain
+    elapsed, votes, last_size = runner.timed(a.steps)
+    host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in runner.host_s.items()}
+    runner.set_opts(opts_plain)
     kern = None
-    if timing:
-        kern = timing.collect()                # the dominant kernel's per-launch durations from the timed region itself
-        timing.close()
-        if True:                               # every kernel kind, from a short pass of its own straight after
-            kb = max(3, min(a.steps, 20))
-            t_all = _hip.Timing(6 * n_chunks * kb + 16)
-            o_all = t_all.opts(flags)
-            for lane in lanes:
-                lane["eng"].opts = o_all
-            run(kb)
-            torch.cuda.synchronize()
-            for k_, v_ in t_all.collect().items():
-                if k_ != DOMINANT or not kern[k_]["launches"]:
-                    kern[k_] = v_
-            for lane in lanes:
-                lane["eng"].opts = opts_plain
-            t_all.close()
+    if not a.no_kernel_events:
+        kern = {}
+        if timing:
+            kern = timing.collect()            # the dominant kernel's per-launch durations from the timed region itself
+            timing.close()
+        # every kernel kind, from a short pass of its own straight after (plain launches, a pair on every one)
+        kb = max(3, min(a.steps, 20))
+        t_all = _hip.Timing(8 * n_chunks * kb + 16)
+        runner.set_opts(t_all.opts(flags))
+        runner.run(kb)
+        torch.cuda.synchronize()
+        for k_, v_ in t_all.collect().items():
+            if k_ != DOMINANT or not kern.get(k_, {}).get("launches"):
+                kern[k_] = v_
+        runner.set_opts(opts_plain)
+        t_all.close()
 
     # correctness of what was timed: every frame's payload, every segment's vote (and the leak's copy sequence)
-    want_mine = np.stack([expected[s] for s in seg_global[first:first + n]]) if n else np.zeros((0, PAYLOAD.size), np.int64)
-    got_mine = mine.cpu().numpy()
+    want_mine = job.expected_rows[job.first:job.first + n] if n else np.zeros((0, L), np.uint8)
+    got_mine = lanes[0].pay[0].cpu().numpy() if n else np.zeros((0, L), np.uint8)
     ber = float((got_mine != want_mine).mean()) if n else 0.0
-    votes_ok = len(votes) == len(expected) and all(v[0] is not None and np.array_equal(v[0], expected[s]) for s, v in votes.items())
+    votes_ok = runner.votes_ok(votes, last_size)
     payload_ok = bool((got_mine == want_mine).all())
     if cfg == 5:     # under the noise attack single frames may misread; what must hold is the vote -> copy sequence
-        votes_ok = votes_ok and fp.identify_copies({s + 1: v for s, v in votes.items()}) == chosen
         payload_ok = votes_ok
 
     extra = {}
-    if cfg == 5 and world == 1 and not a.no_extras and n:
-        extra["attacks"] = attack_suite(torch, lanes[0]["eng"], leak_sample, keep, [expected[s] for s in range(S)], chosen, fp,
-                                        vote_segments, deg, N, a.alpha, H, W)
+    if cfg == 5 and world == 1 and not a.no_extras and n and not emu:
+        e0 = lanes[0].eng
+        det = (lambda x: e0.detect(x, L, alpha=a.alpha)[0]) if a.codec == "dct" else (lambda x: e0.svd_detect(x, L, scale=15, blk=a.blk)[0])
+        extra["attacks"] = attack_suite(torch, det, job.leak_sample, job.keep, [job.expected[s] for s in range(S)], job.chosen, fp,
+                                        vote_segments, deg, n_bits, H, W, "DCT" if a.codec == "dct" else f"DwtDctSvd(blk={a.blk})")
     # the same K steps once more, straight after the timed region.  `value` is the contract's figure (W warm-up steps after
     # idle, then K steps: with a short K that sits on the device's clock ramp); this one is the rate the device settles at.
     if not a.no_extras:
-        el_b, v_b, _ = timed(a.steps)
-        extra["value_second_pass"] = round(total_frames * a.steps / el_b, 1)
-        extra["second_pass"] = dict(steps=a.steps, ms_per_step=round(1e3 * el_b / a.steps, 4),
-                                    votes_ok=len(v_b) == len(expected) and all(v[0] is not None and np.array_equal(v[0], expected[s])
-                                                                               for s, v in v_b.items()),
+        el_b, v_b, sz_b = runner.timed(a.steps)
+        extra["value_second_pass"] = round((n if emu else job.total_frames) * a.steps / el_b, 1)
+        extra["second_pass"] = dict(steps=a.steps, ms_per_step=round(1e3 * el_b / a.steps, 4), votes_ok=runner.votes_ok(v_b, sz_b),
                                     note="the same K steps again straight after the timed region (no event pairs on the launches)")
 
-    # the same steps alternating between TWO HIP streams (own workspace and output buffer each): independent batches overlap, one
-    # step's analyze beside the other's mark+verify, launch gaps and kernel tails filled.  Measured: +5 % over a single stream whose
-    # every launch carries an event pair, 0 to +2 % over the eventless single stream (`value_second_pass`): most of what it hides is
-    # instrumentation.  Reported next to `value`, which stays single-stream: under concurrency a kernel's launch duration includes
-    # the time it shares the device, so the roofline object (bytes per launch / launch duration) would no longer describe the kernel.
-    if cfg in (2, 3) and a.codec == "dct" and a.streams == 1 and not a.no_extras and n:
+    # ---- the fused mark kernel in BOTH tile orders, same K steps, interleaved in this process (VERDICT r3 item 1) ----
+    if a.codec == "dct" and mode == "embed_detect" and not planar and not a.separate_detect and not a.no_extras and n and not a.no_kernel_events:
         try:
-            lanes.append(dict(eng=DctEngine(device=dev, chunk_frames=chunk, opts=opts_plain),
-                              out=torch.empty_like(frames) if out is not None else None, stream=torch.cuda.Stream()))
-            lanes[1]["eng"].opts = lanes[0]["eng"].opts
-            lanes[1]["eng"].workspace(H, W, lanes[1]["eng"]._chunk(n, H, W))
-            run(2)
-            el_t, v_t, _ = timed(a.steps)
-            extra["value_two_streams"] = round(total_frames * a.steps / el_t, 1)
+            shipped = lanes[0].eng.tile_order
+            info = lanes[0].eng.tile_order_info
+            t_ab = _hip.Timing(2 * n_chunks * a.steps + 16, 1 << _hip.TIMING_KINDS.index("mark_fused"))
+            runner.set_opts(t_ab.opts(flags))
+            res = {"xcd": [], "linear": []}
+            for order in ("xcd", "linear", "linear", "xcd"):
+                runner.set_order(order)
+                runner.run(1)
+                torch.cuda.synchronize()
+                t_ab.collect()
+                el_o, _, _ = runner.timed(a.steps)
+                kk = t_ab.collect()["mark_fused"]
+                res[order].append((1e3 * el_o / a.steps, kk["ms_total"] / max(kk["launches"], 1)))
+            runner.set_order(a.tile_order)
+            runner.set_opts(opts_plain)
+            t_ab.close()
+            extra["mark_order"] = dict(
+                xcd_ms=round(float(np.mean([k for _, k in res["xcd"]])), 5), linear_ms=round(float(np.mean([k for _, k in res["linear"]])), 5),
+                xcd_step_ms=round(float(np.mean([s_ for s_, _ in res["xcd"]])), 4), linear_step_ms=round(float(np.mean([s_ for s_, _ in res["linear"]])), 4),
+                shipped=shipped, mode=a.tile_order, calibration={k: v for k, v in info.items() if k not in ("mode", "in_use")},
+                xcc_deal=engine_mod.probe_xcc_deal(dev),
+                note=f"fused mark kernel, average launch duration over 2 x {a.steps} steps per order, run xcd / linear / linear / xcd after the "
+                     "timed region; `shipped` is what the timed region used (auto = the engine's calibration at set-up)")
+        except Exception as exc:
+            extra["mark_order"] = dict(error=repr(exc))
+            runner.set_order(a.tile_order)
+            runner.set_opts(opts_plain)
+
+    # ---- emulation of an M-rank job: the whole job on this GPU, for the predicted speed-up --------------------------
+    if emu:
+        full = Runner(job_full, n_lanes=1, group=1, graph=False, emulate=False)
+        full.prepare()
+        full.run(max(1, a.warmup))
+        el_f, v_f, sz_f = full.timed(a.steps)
+        el_f2, _, _ = full.timed(a.steps)
+        el_f = min(el_f, el_f2)
+        full_ms = 1e3 * el_f / a.steps
+        shard_ms = 1e3 * min(elapsed, el_b if not a.no_extras else elapsed) / a.steps
+        speed = full_ms / shard_ms * (emu if job.scaling == "weak" else 1)
+        extra["emulation"] = dict(
+            world=emu, shard_frames=n, total_frames=job.total_frames, steps_per_host_iteration=G, hipgraph=bool(use_graph),
+            shard_ms_per_step=round(shard_ms, 4), host_ms_per_step=host_ms, full_job_ms_per_step=round(full_ms, 4),
+            full_job_votes_ok=full.votes_ok(v_f, sz_f), predicted_speedup=round(speed, 2),
+            predicted_frames_per_s=round(job.total_frames / (shard_ms * 1e-3), 1),
+            note=f"rank 0 of {emu}: its shard's embed/detect/payloads, a device copy into the pre-filled [{emu}, G, n, L] buffer where the RCCL "
+                 f"all-gather would be, download, vote over all {job.total_frames} payloads per step; predicted speed-up = "
+                 + ("M x " if job.scaling == "weak" else "") + "T(whole job on this GPU) / T(rank 0's step), best of two passes each.  Not modelled: the real "
+                 "all-gather's latency (side stream, off the critical path) and N processes sharing the host")
+        del full
+
+    # the same steps alternating between TWO HIP streams (own workspace and output buffer each): independent batches overlap, one
+    # step's analyze beside the other's mark+verify, launch gaps and kernel tails filled.  Reported next to `value`, which stays
+    # single-stream: under concurrency a kernel's launch duration includes the time it shares the device, so the roofline object
+    # (bytes per launch / launch duration) would no longer describe the kernel.
+    if cfg in (2, 3) and a.codec == "dct" and a.streams == 1 and not a.no_extras and n and not planar and not emu:
+        try:
+            runner.add_lane(torch.cuda.Stream())
+            lanes[1].eng.workspace(H, W, lanes[1].eng._chunk(n, H, W))
+            runner.run(2)
+            el_t, v_t, sz_t = runner.timed(a.steps)
+            extra["value_two_streams"] = round(job.total_frames * a.steps / el_t, 1)
             extra["two_streams"] = dict(steps=a.steps, ms_per_step=round(1e3 * el_t / a.steps, 4),
-                                        path_frac_of_peak=round(total_frames * a.steps / el_t * 9 * H * W / 1e9 / (HBM_PEAK_GBPS * world), 4),
-                                        votes_ok=len(v_t) == len(expected) and all(v[0] is not None and np.array_equal(v[0], expected[s])
-                                                                                   for s, v in v_t.items()),
+                                        path_frac_of_peak=round(job.total_frames * a.steps / el_t * 9 * H * W / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                                        votes_ok=runner.votes_ok(v_t, sz_t),
                                         note="the same K steps, consecutive steps on two HIP streams (python bench.py --streams 2 times this form)")
         except Exception as exc:                               # e.g. no room for the second output buffer
             extra["two_streams"] = dict(error=repr(exc))
@@ -545,39 +834,39 @@ def main():
                 torch.cuda.synchronize()
                 lanes.pop()
 
+    side_ok = cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras and not planar and not emu
     # second figure of the same line: SURVEY 8d config 2 read literally (embed, then the stand-alone detect)
-    if cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras:
-        sep = _hip.Opts(_hip.F_SEPARATE_DETECT, 0, None)
-        for lane in lanes:
-            lane["eng"].opts = sep
+    if side_ok:
+        runner.set_opts(_hip.Opts(_hip.F_SEPARATE_DETECT, 0, None))
         k2 = max(3, min(a.steps, 20))
-        run(1)
-        el2, v2, _ = timed(k2)
-        for lane in lanes:
-            lane["eng"].opts = opts_plain
+        runner.run(1)
+        el2, v2, sz2 = runner.timed(k2)
+        runner.set_opts(opts_plain)
         extra["value_separate_detect"] = round(world * n * k2 / el2, 1)
         extra["separate_detect"] = dict(steps=k2, ms_per_step=round(1e3 * el2 / k2, 4),
                                         note="embed, then the stand-alone detect on the written frames (12 B/px real traffic); "
-                                             "bit-identical results",
-                                        votes_ok=all(np.array_equal(v[0], expected[s]) for s, v in v2.items()))
+                                             "bit-identical results", votes_ok=runner.votes_ok(v2, sz2))
+
+    def side_rate(step, k):
+        step()
+        runner.fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            pm = step()
+        runner.fence()
+        return time.perf_counter() - t0, pm
 
     # planar 4:2:0 frames through the same step, HBM-resident: what the fused ingest/egress costs or saves
-    if cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras and H % 8 == 0 and W % 8 == 0:
-        e0 = lanes[0]["eng"]
-        planes = e0.rgb_to_yuv420(frames)
+    if side_ok and H % 8 == 0 and W % 8 == 0:
+        e0 = lanes[0].eng
+        planes = e0.rgb_to_yuv420(job.frames)
         pout = torch.empty_like(planes)
 
         def planar_step():
-            _, c, _ = e0.embed_detect_yuv420(planes, H, W, wm_dev, PAYLOAD.size, alpha=a.alpha, out=pout)
+            _, c, _ = e0.embed_detect_yuv420(planes, H, W, job.wm_dev, L, alpha=a.alpha, out=pout)
             return e0.payloads(c, N, perm_dev)
-        planar_step()
-        fence()
-        t0 = time.perf_counter()
         k3 = max(3, min(a.steps, 20))
-        for _ in range(k3):
-            pm = planar_step()
-        fence()
-        el3 = time.perf_counter() - t0
+        el3, pm = side_rate(planar_step, k3)
         extra["planar_i420"] = dict(value=round(world * n * k3 / el3, 1), unit="frames/s", steps=k3, ms_per_step=round(1e3 * el3 / k3, 4),
                                     payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
                                     note="embed+detect on I420 planes (1.5 B/px in, 1.5 B/px out, conversion fused into the kernels); "
@@ -585,39 +874,19 @@ def main():
         del planes, pout
 
     # the codec tests/mark.py and tests/detect.py construct, same frames, same step: embed + verify + payloads
-    if cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras:
-        e0 = lanes[0]["eng"]
-
-        def svd_step():
-            _, c, _ = e0.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, wm_row=rows_dev, out=out)
-            return e0.payloads(c, N, perm_dev)
-        svd_step()
-        fence()
-        t0 = time.perf_counter()
+    if side_ok:
+        e0 = lanes[0].eng
         k4 = max(3, min(a.steps, 20))
-        for _ in range(k4):
-            pm = svd_step()
-        fence()
-        el4 = time.perf_counter() - t0
-        extra["dwtdctsvd"] = dict(value=round(world * n * k4 / el4, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el4 / k4, 4),
-                                  payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
-                                  algorithmic_GBps=round(n * k4 * 6 * H * W / el4 / 1e9, 1),
-                                  note="DwtDctSvd embed + verify + payloads in one 6 B/px pass (scale 15)")
-        # the same codec with blk=8 (16x16 pixel tiles, an 8x8 singular-triplet solve per tile; H*W/256 bits per frame)
-        def svd8_step():
-            _, c, _ = e0.svd_embed_detect(frames, wm_dev, L=PAYLOAD.size, scale=15, wm_row=rows_dev, out=out, blk=8)
-            return e0.payloads(c, H * W // 256, perm_dev)
-        svd8_step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(k4):
-            pm = svd8_step()
-        fence()
-        el5 = time.perf_counter() - t0
-        extra["dwtdctsvd_blk8"] = dict(value=round(world * n * k4 / el5, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el5 / k4, 4),
-                                       payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
-                                       algorithmic_GBps=round(n * k4 * 6 * H * W / el5 / 1e9, 1),
-                                       note="DwtDctSvd(blk=8) embed + verify + payloads (16x16 pixel tiles; the tile is read twice, the second time from cache)")
+        for blk, key in ((4, "dwtdctsvd"), (8, "dwtdctsvd_blk8")):
+            def svd_step(blk=blk):
+                _, c, _ = e0.svd_embed_detect(job.frames, job.wm_dev, L=L, scale=15, wm_row=job.rows_dev, out=lanes[0].out, blk=blk)
+                return e0.payloads(c, DctEngine.svd_bits_per_frame(H, W, blk), perm_dev)
+            el4, pm = side_rate(svd_step, k4)
+            extra[key] = dict(value=round(world * n * k4 / el4, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el4 / k4, 4),
+                              payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
+                              algorithmic_GBps=round(n * k4 * 6 * H * W / el4 / 1e9, 1),
+                              note="DwtDctSvd embed + verify + payloads in one 6 B/px pass (scale 15)" if blk == 4 else
+                                   "DwtDctSvd(blk=8) embed + verify + payloads (16x16 pixel tiles, an 8x8 singular-triplet solve per tile; H*W/256 bits per frame)")
 
     if rank != 0:
         if world > 1:
@@ -627,11 +896,10 @@ def main():
 
     # what the device is doing under this load: one rocm-smi sample (engine clock, socket power) while the steps keep running --
     # the evidence behind "the socket sits on its power limit" travels with the line
-    if cfg == 2 and a.codec == "dct" and world == 1 and not a.no_extras:
+    if side_ok and world == 1:
         try:
             import re
             import shutil
-            import subprocess
             import threading
             smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
             stop = threading.Event()
@@ -640,7 +908,7 @@ def main():
                 torch.cuda.set_device(dev)
                 while not stop.is_set():
                     for _ in range(50):
-                        hot_path(lanes[0]["eng"], lanes[0]["out"])
+                        runner.hot_path(lanes[0])
                     torch.cuda.synchronize()
             th = threading.Thread(target=keep_busy, daemon=True)
             th.start()
@@ -658,13 +926,13 @@ def main():
             extra["device_under_load"] = dict(error=repr(exc))
 
     # PCIe-inclusive rate (never `value`): frames start and end in pinned host memory, three-stream pipeline
-    if cfg == 2 and a.codec == "dct" and world == 1 and not a.no_extras and (H, W) == (1080, 1920):
+    if side_ok and world == 1 and (H, W) == (1080, 1920):
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import pcie_pipeline
             pc = {}
             for fmt in ("rgb24", "i420"):
-                f_, g_ = pcie_pipeline.measure(fmt, n=200, B=50, H=H, W=W, eng=lanes[0]["eng"])
+                f_, g_ = pcie_pipeline.measure(fmt, n=200, B=50, H=H, W=W, eng=lanes[0].eng)
                 pc[fmt] = dict(frames_per_s=round(f_, 1), GBps_each_way=round(g_, 2))
             extra["pcie_inclusive"] = dict(pc, note="embed+verify with every frame crossing PCIe in and out (pinned host memory, "
                                                     "H2D / kernels / D2H on three streams); tools/pcie_pipeline.py")
@@ -682,10 +950,17 @@ def main():
                                                      "threaded host copies per frame)")
         except Exception as exc:
             extra["plugin_pipeline"] = dict(error=repr(exc))
+    # the literal per-frame plugin boundary on host float32 YUV frames
+    if side_ok and world == 1:
+        try:
+            extra["plugin_yuv32f"] = plugin_yuv32f_rates(H, W, a.alpha, job.frames[0].cpu().numpy())
+        except Exception as exc:
+            extra["plugin_yuv32f"] = dict(error=repr(exc))
 
     # achievable HBM bandwidth of this device, same run: 16-byte streaming copy (read + write) and read-only stream
-    if frames.numel() >= (1 << 28) and out is not None:
-        probe_src, probe_dst = frames, out
+    out0 = lanes[0].out
+    if job.frames.numel() >= (1 << 28) and out0 is not None and out0.numel() == job.frames.numel():
+        probe_src, probe_dst = job.frames, out0
     else:
         probe_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 256)
         probe_dst = torch.empty_like(probe_src)
@@ -707,18 +982,22 @@ def main():
     copy_gbps = probe(lambda: _hip.check(lib.ofmk_hbm_copy(probe_src.data_ptr(), probe_dst.data_ptr(), nbytes, s)), 2 * nbytes)
     read_gbps = probe(lambda: _hip.check(lib.ofmk_hbm_read(probe_src.data_ptr(), nbytes, sink.data_ptr(), s)), nbytes)
 
-    fps = total_frames * a.steps / elapsed
+    units = n if emu else job.total_frames                  # emulation: `value` is what this ONE GPU really processed
+    fps = units * a.steps / elapsed
     frame_bytes = 3 * H * W
     roof = None
     sha = source_sha16()
     if kern:
         # algorithmic bytes per frame and kernel: analyze reads the frame (3 B/px);
         # mark reads it again and writes the marked frame (6 B/px); the fused mark+verify kernel
-        # moves the same 6 B/px and spares detect's 3 B/px read.  Sum over a step = 9 B/px.
-        alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes, "svd": 2 * frame_bytes}
+        # moves the same 6 B/px and spares detect's 3 B/px read.  Sum over a step = 9 B/px.  Planar 4:2:0: half of each.
+        svd_bytes = frame_bytes if mode == "detect" else 2 * frame_bytes
+        alg = {"analyze": frame_bytes, "mark": 2 * frame_bytes, "mark_fused": 2 * frame_bytes, "svd": svd_bytes,
+               "planar_analyze": frame_bytes // 2, "planar_mark": frame_bytes}
+        svd_name = ("svd8_rgb8_kernel" if a.blk == 8 else "svd_rgb8_kernel") + ("<detect>" if mode == "detect" else "<embed+verify>")
         names = {"analyze": "analyze_kernel<rgb8>", "mark": "mark_rgb8_kernel", "mark_fused": "mark_rgb8_kernel<fused verify>",
-                 "svd": "svd_rgb8_kernel<embed+verify>"}
-        ceiling = {"analyze": read_gbps, "mark": copy_gbps, "mark_fused": copy_gbps, "svd": copy_gbps}
+                 "svd": svd_name, "planar_analyze": f"analyze_yuv420_kernel<{a.pixfmt}>", "planar_mark": f"mark_yuv420_kernel<{a.pixfmt}, fused verify>"}
+        ceiling = {"analyze": read_gbps, "planar_analyze": read_gbps}
         per = {}
         for k, v in kern.items():
             if not v["launches"]:
@@ -731,62 +1010,62 @@ def main():
                 d["algorithmic_bytes_per_launch"] = int(frames_per_launch * alg[k])
                 d["achieved_GBps"] = round(frames_per_launch * alg[k] / (avg_ms * 1e-3) / 1e9, 1)
                 d["frac_of_peak"] = round(d["achieved_GBps"] / HBM_PEAK_GBPS, 4)
-                d["frac_of_measured_" + ("read" if k == "analyze" else "copy")] = round(d["achieved_GBps"] / ceiling[k], 4)
+                d["frac_of_measured_" + ("read" if k in ceiling else "copy")] = round(d["achieved_GBps"] / ceiling.get(k, copy_gbps), 4)
             per[k] = d
         extra["kernels"] = per
-        extra["kernels_note"] = (f"{DOMINANT}: event pairs on its launches in the timed region; the other kinds: a pass of "
-                                 f"{max(3, min(a.steps, 20))} steps straight after it with a pair on every launch")
+        extra["kernels_note"] = ((f"{DOMINANT}: event pairs on its launches in the timed region; the other kinds: " if timing else
+                                  "the timed region replays a captured hipGraph (no events on graph nodes); every kind: ")
+                                 + f"a pass of {max(3, min(a.steps, 20))} steps straight after it with a pair on every launch")
         extra["kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in per.values()), 4)
-        dom = DOMINANT if DOMINANT in per else max((k for k in per if k in alg), key=lambda k: per[k]["ms_per_step"])
-        achieved = per[dom]["achieved_GBps"]
-        # PMC-measured HBM bytes per launch (separate rocprofv3 passes, tools/prof.sh): quoted only when that profile
-        # was taken from exactly these kernel sources and this frame size
-        traffic, traffic_src = None, None
-        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
-            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if tj.get("source_sha16") == sha and (tj["height"], tj["width"]) == (H, W) and dom in tj:
-                per_frame = (tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]) / tj["frames_per_dispatch"]
-                traffic = int(per_frame * per[dom]["algorithmic_bytes_per_launch"] / alg[dom])
-                traffic_src = f"profiles/{name} (source {sha})"
-                break
-        roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=per[dom]["algorithmic_bytes_per_launch"],
-                    avg_launch_ms=per[dom]["avg_launch_ms"], launches=per[dom]["launches"],
-                    frac_of_measured_copy=round(achieved / copy_gbps, 4),
-                    frac_of_measured_read=round(achieved / read_gbps, 4))
+        if per:
+            dom = DOMINANT if DOMINANT in per else max((k for k in per if k in alg), key=lambda k: per[k]["ms_per_step"])
+            achieved = per[dom]["achieved_GBps"]
+            # PMC-measured HBM bytes per launch (separate rocprofv3 passes, tools/prof.sh): quoted only when that profile
+            # was taken from exactly these kernel sources and this frame size
+            traffic, traffic_src = None, None
+            for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if tj.get("source_sha16") == sha and (tj["height"], tj["width"]) == (H, W) and dom in tj \
+                        and names[dom].split("<")[0] in tj.get("kernel_names", {}).get(dom, names[dom]):
+                    per_frame = (tj[dom]["fetch_bytes"] + tj[dom]["write_bytes"]) / tj["frames_per_dispatch"]
+                    traffic = int(per_frame * per[dom]["algorithmic_bytes_per_launch"] / alg[dom])
+                    traffic_src = f"profiles/{name} (source {sha})"
+                    break
+            roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=per[dom]["algorithmic_bytes_per_launch"],
+                        avg_launch_ms=per[dom]["avg_launch_ms"], launches=per[dom]["launches"],
+                        frac_of_measured_copy=round(achieved / copy_gbps, 4),
+                        frac_of_measured_read=round(achieved / read_gbps, 4))
 
-    base = None
-    if world == 1 and not a.no_cpu_baseline and a.codec == "dct" and mode == "embed_detect":
-        try:
-            nb = 96 if H * W <= 1920 * 1080 else 24
-            wm_cpu = Shuffler(key=0).generate_wm(PAYLOAD, (1, N))
-            base = cpu_baseline(synthetic_frames(nb, H, W, seed=2000, device=dev).cpu().numpy(), wm_cpu, a.alpha, a.cpu_seconds)
-        except Exception as exc:                       # e.g. no C compiler on the box: report, do not lose the GPU line
-            base = dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"cpu baseline failed: {exc!r}")
-
-    # 9 B/px per embed+detect frame with the DCT codec; the DwtDctSvd codec has no frame-global
+    # 9 B/px per embed+detect frame with the DCT codec (4.5 on 4:2:0 planes); the DwtDctSvd codec has no frame-global
     # dependency and no separate detect read: 6 B/px; detect only: 3 B/px
-    bpp = 3 if mode == "detect" else 9 if a.codec == "dct" else 6
+    bpp = 3 if mode == "detect" else (4.5 if planar else 9) if a.codec == "dct" else 6
     path_gbps = fps * bpp * H * W / 1e9
     what = {2: "configs[1]", 3: "configs[2]", 4: "configs[3]", 5: "configs[4]"}[cfg]
     op = "embed+detect" if mode == "embed_detect" else "leak detect"
+    codec_name = "DCT" if a.codec == "dct" else (f"DwtDctSvd(blk={a.blk})" if a.blk != 4 else "DwtDctSvd")
+    sw = job.shard_world
     if cfg in (2, 3):
-        workload = f"synthetic {W}x{H} u8 RGB x{n} frames per GPU, "
+        workload = f"synthetic {W}x{H} u8 {'RGB' if not planar else a.pixfmt.upper() + ' planes'} x{n} frames per GPU, "
     else:
-        workload = (f"synthetic {W}x{H} u8 RGB, {S} segments x {F} frames sharded over {world} rank(s), "
+        workload = (f"synthetic {W}x{H} u8 RGB, {S} segments x {F} frames sharded over {sw} rank(s), "
                     + ("own payload per segment, " if cfg == 4 else f"{C} copies per segment, leak 01201201 + N(0,2) noise, "))
+    if emu:
+        workload = f"RANK 0 OF AN EMULATED {emu}-RANK JOB on one GPU: " + workload
+
     line = {
         "metric": f"1080p frames/sec {op}" if (H, W) == (1080, 1920) else f"{W}x{H} frames/sec {op}",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": scaling,
+        "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": job.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload + f"{'DCT' if a.codec == 'dct' else 'DwtDctSvd'} {op}+vote (BASELINE.json {what})",
-                   "codec": a.codec, "frames_per_gpu": n, "payload_bits": int(PAYLOAD.size), "alpha": a.alpha,
-                   "chunk_frames": chunk,
+        "config": {"workload": workload + f"{codec_name} {op}+vote (BASELINE.json {what})",
+                   "codec": a.codec, "frames_per_gpu": n, "payload_bits": L, "alpha": a.alpha,
+                   "chunk_frames": chunk, "chunks_per_step": n_chunks, "steps_per_host_iteration": G, "hipgraph": bool(use_graph),
+                   "tile_order": lanes[0].eng.tile_order if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")
-                   if a.codec == "dct" else "fused into the embed kernel",
-                   "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {world} rank(s), one RCCL all-gather of payloads"},
+                   if a.codec == "dct" else ("stand-alone kernel" if mode == "detect" else "fused into the embed kernel"),
+                   "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {sw} rank(s), one RCCL all-gather of payloads"},
         "payload_ber": ber, "payload_bit_exact": payload_ok and votes_ok,
         "roofline": roof,
         "path": {"algorithmic_GBps": round(path_gbps, 1), "bytes_per_frame": bpp * H * W,
@@ -798,13 +1077,23 @@ def main():
                        "self_launched": bool(os.environ.get("OFMK_BENCH_SELF_LAUNCHED"))},
         "rccl_ranks": ranks_seen if (grouped and a.backend == "nccl") else None,
         "host_ms_per_step": host_ms,            # rank 0's CPU time issuing a step / voting on one; must stay < ms_per_step
-        "cpu_baseline": base,
+        "cpu_baseline": None,
     }
     line.update(extra)
-    print(json.dumps(line), flush=True)
+
+    # every rank is past its timed region and its side measurements: let the others go BEFORE the CPU baseline occupies this
+    # host for tens of seconds (so N > 1 lines carry it too), then print the one line
     if grouped:
         barrier()
         dist.destroy_process_group()
+    if not a.no_cpu_baseline and a.codec == "dct" and mode == "embed_detect":
+        try:
+            nb = 96 if H * W <= 1920 * 1080 else 24
+            wm_cpu = Shuffler(key=0).generate_wm(PAYLOAD, (1, N))
+            line["cpu_baseline"] = cpu_baseline(synthetic_frames(nb, H, W, seed=2000, device=dev).cpu().numpy(), wm_cpu, a.alpha, a.cpu_seconds)
+        except Exception as exc:                       # e.g. no C compiler on the box: report, do not lose the GPU line
+            line["cpu_baseline"] = dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"cpu baseline failed: {exc!r}")
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@
  *     compute call may be captured into a hipGraph (unless it carries an ofmk_timing object);
  *   - re-entrant: the library has NO mutable state besides the calling thread's error text.
  *     Everything a call needs arrives in its arguments; per-call options travel in `ofmk_opts`
- *     (NULL = defaults), the LAST argument of EVERY compute entry point (ABI 3; only the
+ *     (NULL = defaults), the LAST argument of EVERY compute entry point (since ABI 3; only the
  *     bandwidth probes and the timing-object functions at the end of this file take none).  Two host threads may drive two engines (own workspace, own stream,
  *     own timing object) concurrently (tests/test_gpu_parity.py::test_two_threads_two_engines);
  *   - return value 0 = OK, negative = error (OFMK_E_*); ofmk_last_error() gives the text for
@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OFMK_ABI_VERSION 3
+#define OFMK_ABI_VERSION 4
 
 #define OFMK_OK            0
 #define OFMK_E_ARG        -1   /* null pointer / non-positive size / H or W < 8 */
@@ -50,13 +50,23 @@ const char *ofmk_last_error(void);
 typedef struct ofmk_timing ofmk_timing;     /* opaque, see ofmk_timing_create */
 typedef struct ofmk_opts {
     uint32_t flags;          /* OFMK_F_*; unknown bits are rejected (OFMK_E_ARG) */
-    uint32_t reserved;       /* must be 0 (rejected otherwise) */
+    uint32_t xcds;           /* XCDs the XCD-aware tile order assumes: 0 = 8 (MI355X, SPX mode), 1 = linear order, > 64 rejected.
+                                ABI 3 called this word `reserved` and required 0: an ABI-3 caller gets ABI 3's behaviour */
     ofmk_timing *timing;     /* NULL = launches carry no events */
 } ofmk_opts;
 /* ofmk_embed_detect_rgb8: embed, then detect the written frames with the stand-alone detect kernels
  * (analyze runs on the marked frames: 12 B/px of traffic) instead of the fused mark+verify kernel
  * (9 B/px).  Same results bit for bit. */
 #define OFMK_F_SEPARATE_DETECT 1u
+/* Tile order of the frame-WRITING DCT kernel (ofmk_embed_rgb8, ofmk_embed_detect_rgb8, ofmk_stage_mark_rgb8).  The kernel is
+ * one linear grid of 48 KiB tiles; the hardware deals consecutive workgroups round-robin to the XCDs.  Default: XCD-aware
+ * order, every XCD walks one contiguous 1/xcds of the batch (tile = (L % xcds) * ceil(G / xcds) + L / xcds); with this flag:
+ * tile = workgroup index.  A pure permutation of the work: results are identical bit for bit either way; which one is
+ * faster differs from box to box by a few per cent (BENCH_r02 / r03), so the Python engine picks it per device with a
+ * calibration (offmark/engine.py: calibrate_tile_order) and bench.py reports both.  The read-only and one-pass kernels
+ * always run in linear order (measured faster there).  The reference has no counterpart: its loop is one frame at a
+ * time (src/offmark/video/embedder.py:18-31). */
+#define OFMK_F_LINEAR_TILES 2u
 
 /* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
  * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to
@@ -220,14 +230,19 @@ int ofmk_stage_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W,
 int ofmk_hbm_copy(const void *src, void *dst, size_t bytes, void *stream);
 int ofmk_hbm_read(const void *src, size_t bytes, void *sink, void *stream);
 
+/* Which XCD each workgroup of a linear grid of `n_workgroups` 64-thread workgroups runs on (HW_REG_XCC_ID): device int32
+ * [n_workgroups].  HIP promises nothing about that deal; the XCD-aware tile order assumes workgroups L and L + xcds share an
+ * XCD (speed only, never correctness), and this lets a host check it and count the XCDs (bench.py: `mark_order.xcc_deal`). */
+int ofmk_probe_xcc(int32_t *xcc_of_workgroup, int n_workgroups, void *stream, const ofmk_opts *opts);
+
 /* Per-launch HIP-event timing for bench.py.  A timing object owns 2*max_launches events; while it is passed in
  * ofmk_opts.timing every launch of a kernel kind selected in kind_mask (bit k = kind k, 0 = all) carries an event
  * pair as the dispatch's own start/stop events (hipExtLaunchKernelGGL) on the launch stream, so no marker packets
  * separate consecutive kernels.  collect() waits for the recorded events, returns the summed milliseconds and
- * launch counts per kernel kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze, 4 DwtDctSvd, 5 planar
- * 4:2:0 kernels) and rewinds the pool.  One object per engine / host thread; a call that carries one cannot be
+ * launch counts per kernel kind (0 analyze, 1 finalize, 2 mark, 3 fused mark+analyze, 4 DwtDctSvd, 5 planar 4:2:0
+ * analyze, 6 planar 4:2:0 mark) and rewinds the pool.  One object per engine / host thread; a call that carries one cannot be
  * captured into a hipGraph (events on the dispatch). */
-#define OFMK_TIMING_KINDS 6
+#define OFMK_TIMING_KINDS 7
 int ofmk_timing_create(int max_launches, unsigned kind_mask, ofmk_timing **out);
 int ofmk_timing_collect(ofmk_timing *t, double *ms_by_kind /*[OFMK_TIMING_KINDS]*/, int *launches_by_kind /*[OFMK_TIMING_KINDS]*/);
 void ofmk_timing_destroy(ofmk_timing *t);

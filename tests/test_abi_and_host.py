@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
                 and ("ofmk" in l or " g_" in l) and "(" not in l          # "name(args)" = a kernel's launch handle
                 and "g_err" not in l and "guard variable" not in l]
     assert not writable, writable
-    assert lib.ofmk_version() == _hip.ABI_VERSION == 3
+    assert lib.ofmk_version() == _hip.ABI_VERSION == 4
     # pure host-side entry points are safe to call without a GPU
     assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 32 * 8 + 4096
     assert lib.ofmk_workspace_bytes(0, 1080, 1920) == 0 and lib.ofmk_workspace_bytes(1, 4, 1920) == 0
@@ -311,7 +311,9 @@ def test_pipeline_host_side_read_ahead_and_writer_protocol():
         got, end = drain(reader)
         assert end is None and [len(g) for g in got] == [4, 4, 3] and np.array_equal(np.concatenate(got), frames)
     got, end = drain(Bare(frames, fail_at=6))
-    assert isinstance(end, IOError) and np.array_equal(np.concatenate(got), frames[:4])       # the complete batch came through first
+    # every frame read before the failure comes through first, the partial batch included (the reference's loop
+    # would have processed them all), then the exception
+    assert isinstance(end, IOError) and [len(g) for g in got] == [4, 2] and np.array_equal(np.concatenate(got), frames[:6])
     got, end = drain(Bare(list(frames[:5]) + [np.zeros((5, 6, 3), np.uint8)]))
     assert isinstance(end, ValueError) and "expected" in str(end)
     got, end = drain(Bare([]))
@@ -334,6 +336,10 @@ def test_pipeline_host_side_read_ahead_and_writer_protocol():
     w.write_batch(buf)
     buf[:] = 0                                                   # the caller reuses its buffer: the writer kept a copy
     assert np.array_equal(np.stack(w.frames), frames[:4])
+    assert np.array_equal(w.array(), frames[:4])                  # array() without a block: the stacked stream, not an error
+    w.write_batch(frames[4:6].astype(np.int32))                  # a non-uint8 batch is cast, as the reference's writer casts
+    assert np.array_equal(w.array(), frames[:6]) and w.array().dtype == np.uint8
+    assert ArrayFrameWriter().array().shape[0] == 0
     assert queue.Queue                                           # (imported for the timeout above)
 
 
@@ -378,3 +384,17 @@ def test_pipeline_batches_are_bounded_in_bytes():
     assert batch_size(64, frame_shape("rgb24", 2160, 3840)) == 21            # 4K: 64 frames would be 1.6 GB per buffer, 9 buffers
     assert batch_size(64, frame_shape("yuv420p", 2160, 3840)) == 43
     assert batch_size(0, (8, 8, 3)) == 1 and batch_size(5, (8, 8, 3)) == 5
+
+
+def test_balanced_chunks():
+    """engine.balanced_chunk: fewest chunks under the cap, all nearly equal (384 under 345 -> 192 + 192)."""
+    import importlib
+    E = importlib.import_module("offmark.engine")
+    assert E.balanced_chunk(384, 345) == 192
+    assert E.balanced_chunk(300, 345) == 300 and E.balanced_chunk(1000, 86) == 84 and E.balanced_chunk(100, 40) == 34
+    assert E.balanced_chunk(1, 5) == 1 and E.balanced_chunk(7, 1) == 1 and E.balanced_chunk(0, 4) == 1
+    for n in range(1, 400, 7):
+        for cap in (1, 3, 17, 64, 345):
+            c = E.balanced_chunk(n, cap)
+            k = -(-n // c)
+            assert 1 <= c <= max(cap, 1) and k == -(-n // min(cap, n)) and n - (k - 1) * c > c - k      # same chunk count as the cap gives; last chunk within k of the rest

@@ -101,7 +101,7 @@ def test_embedder_pipeline_equals_one_direct_batch_call(eng, codec, form):
     emb.start()
     assert emb.frames_marked == n and len(w.frames) == n and r.closed and w.closed
     assert np.array_equal(np.stack(w.frames), want)
-    if form == "pinned":
+    if form in ("pinned", "registered", "pageable"):     # array() is the whole stream, also when the block was too small
         assert np.array_equal(w.array(), want)
 
 
@@ -179,15 +179,16 @@ def test_empty_stream_and_failing_reader(eng):
     ex = Extractor(BareReader([]), dec, DeShuffler(key=0).set_shape(P8.shape))
     ex.start()
     assert ex.patterns == [] and ex.most_common() == (None, None)
-    # the reader dies at frame 9 of 14: the error reaches the caller (no hang, no silent truncation); what was
-    # complete before it is written, in order
+    # the reader dies at its 10th read of 14 frames: the error reaches the caller (no hang, no silent truncation); every
+    # frame read before it (9 of them: two full batches and one frame of the third) is marked and written, in order --
+    # what the reference's one-frame-at-a-time loop would have done before the exception
     src = frames_rgb(14)
     w2 = BareWriter()
     emb2 = Embedder(BareReader(list(src), fail_at=9), enc, w2, batch_frames=4)
     with pytest.raises(IOError, match="decoder died"):
         emb2.start()
-    want = enc.encode_frames_u8(cuda(src[:8])).cpu().numpy()
-    assert emb2.frames_marked == len(w2.frames) == 8
+    want = enc.encode_frames_u8(cuda(src[:9])).cpu().numpy()
+    assert emb2.frames_marked == len(w2.frames) == 9
     assert np.array_equal(np.stack(w2.frames), want)
     # a frame of the wrong size in the middle of the stream is refused, not read out of bounds
     bad = list(src[:6]) + [np.zeros((H + 8, W, 3), np.uint8)]

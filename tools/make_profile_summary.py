@@ -28,7 +28,8 @@ def source_sha16():
 
 
 def short(k):
-    for key, name in (("analyze_yuv420", "analyze_yuv420"), ("mark_yuv420", "mark_yuv420"), ("analyze_kernel", "analyze"),
+    # names = bench.py's timing kinds, so that its `roofline.traffic` finds the dominant kernel of the profiled command
+    for key, name in (("analyze_yuv420", "planar_analyze"), ("mark_yuv420", "planar_mark"), ("analyze_kernel", "analyze"), ("svd8_rgb8", "svd"),
                       ("mark_rgb8_kernel<true, true", "mark_fused"), ("mark_rgb8_kernel<false, true", "mark_fused"), ("mark_rgb8", "mark"),
                       ("finalize", "finalize"), ("copy16", "copy16"), ("read16", "read16"), ("svd_rgb8", "svd"), ("degenerate", "degenerate")):
         if key in k:
@@ -47,18 +48,20 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     csv.writer(f, quoting=csv.QUOTE_ALL).writerows(rows)
 # ---- PMC ----------------------------------------------------------------------------------------------------------
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+kernel_names = {}
 for f in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = short(r["Kernel_Name"]) if "ofmk::" in r["Kernel_Name"] else None
         if name:
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kernel_names.setdefault(name, r["Kernel_Name"].split("(")[0].replace("void ", ""))
 mean = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
 with open(os.path.join(dst, f"{tag}_pmc_summary.txt"), "w") as f:
     f.write(f"# rocprofv3 PMC summary (MI355X, gfx950), kernel sources {sha}.  Five separate passes of:\n#   {cmd}\n"
             "# Mean counter value per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes\n"
             "# of a wide coalesced read (MI355X_MICROARCH.md, HBM section): calibrated below on the copy probe of this run.\n")
     for name, cs in sorted(mean.items()):
-        f.write(name + "\n")
+        f.write(f"{name}    [{kernel_names.get(name, '')}]\n")
         for c, v in sorted(cs.items()):
             f.write(f"   {c:24s} mean {v:16.1f}  n={len(acc[name][c])}\n")
         if "SQ_INSTS_VALU" in cs and cs.get("SQ_WAVES"):
@@ -81,7 +84,7 @@ if "copy16" in mean and mean["copy16"].get("FETCH_SIZE"):
 traffic = {"_comment": "HBM bytes per dispatch from rocprofv3 PMC passes (tools/prof.sh): FETCH_SIZE KiB x 1024 x fetch_correction "
                        "(gfx950 half-count of wide coalesced reads, calibrated on the copy probe in the same run) + WRITE_SIZE KiB x 1024.",
            "source_sha16": sha, "command": cmd, "frames_per_dispatch": frames, "height": H, "width": W,
-           "fetch_correction": round(factor, 4) if factor else 2.0}
+           "fetch_correction": round(factor, 4) if factor else 2.0, "kernel_names": kernel_names}
 fc = factor if factor and 1.8 < factor < 2.2 else 2.0
 for name, cs in mean.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:

@@ -54,7 +54,8 @@ thread_local char g_err[512] = "";     // the ONLY mutable state of the library:
 
 // Optional per-launch HIP-event timing (bench.py).  The event pool is an object the CALLER owns
 // (ofmk_timing_create) and passes in ofmk_opts; no library-wide state.
-enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_SVD = 4, KIND_PLANAR = 5, KIND_COUNT = 6 };
+enum { KIND_ANALYZE = 0, KIND_FINALIZE = 1, KIND_MARK = 2, KIND_MARK_FUSED = 3, KIND_SVD = 4, KIND_PLANAR_ANALYZE = 5, KIND_PLANAR_MARK = 6, KIND_COUNT = 7 };
+static_assert(KIND_COUNT == OFMK_TIMING_KINDS, "timing kinds");
 struct TimingRec { hipEvent_t a, b; int kind; };
 
 }  // namespace
@@ -73,12 +74,16 @@ struct Ctx {
     hipStream_t s;
     ofmk_timing *t;
     unsigned flags;
+    int xcds;         // tile order of the frame-writing DCT kernel: 0 = linear, X = XCD-aware over X XCDs (common.hiph: xcd_tile)
 };
+constexpr int kDefaultXcds = 8;      // MI355X in SPX mode; ofmk_opts.xcds overrides (ofmk_probe_xcc counts the real ones)
 Ctx make_ctx(void *stream, const ofmk_opts *o) {
     Ctx c;
     c.s = static_cast<hipStream_t>(stream);
     c.t = o ? o->timing : nullptr;
     c.flags = o ? o->flags : 0u;
+    c.xcds = (c.flags & OFMK_F_LINEAR_TILES) ? 0 : (o && o->xcds ? (int)o->xcds : kDefaultXcds);
+    if (c.xcds == 1) c.xcds = 0;
     return c;
 }
 
@@ -157,8 +162,8 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
 
 // every entry point that takes ofmk_opts: unknown flag bits or a non-zero reserved word are a caller bug, not a default
 int check_opts(const ofmk_opts *o) {
-    if (o && ((o->flags & ~(uint32_t)OFMK_F_SEPARATE_DETECT) || o->reserved))
-        return fail(OFMK_E_ARG, "ofmk_opts: unknown flag bits or non-zero reserved field%s");
+    if (o && ((o->flags & ~(uint32_t)(OFMK_F_SEPARATE_DETECT | OFMK_F_LINEAR_TILES)) || o->xcds > 64u))
+        return fail(OFMK_E_ARG, "ofmk_opts: unknown flag bits or xcds > 64%s");
     return OFMK_OK;
 }
 
@@ -169,9 +174,10 @@ int check_dims(int n, int H, int W) {
     return OFMK_OK;
 }
 
-Geom make_geom(int H, int W, const Workspace &ws, int frames = 0) {
+Geom make_geom(int H, int W, const Workspace &ws, int frames = 0, int xcds = 0) {
     Geom g;
     g.frames = frames;
+    g.xcds = xcds;
     g.W = W;
     g.wb = W / 8;
     g.inv_wb = 1.0f / (float)g.wb;
@@ -183,12 +189,13 @@ Geom make_geom(int H, int W, const Workspace &ws, int frames = 0) {
 
 dim3 block_grid(const Geom &g, int n) { return dim3((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n); }
 
-// Linear grid of the frame kernels that order their tiles XCD-aware (common.hiph: xcd_tile): tiles x frames workgroups, padded
-// to a multiple of the 8 XCDs; the kernels take the frame count from their geometry argument.
-dim3 xcd_grid(int blocks_per_frame, int n) {
+// Linear grid of the frame kernels (common.hiph: xcd_tile): tiles x frames workgroups, padded to a multiple of the XCD count
+// the tile order assumes (xcds <= 1: linear order, no padding); the kernels take the frame count from their geometry argument.
+dim3 xcd_grid(int blocks_per_frame, int n, int xcds = 0) {
     const unsigned tiles = (unsigned)((blocks_per_frame + kThreads - 1) / kThreads);
     const unsigned long long G = (unsigned long long)tiles * (unsigned)n;
-    return dim3((unsigned)(((G + kXcds - 1) / kXcds) * kXcds));
+    const unsigned long long X = xcds > 1 ? (unsigned long long)xcds : 1ull;
+    return dim3((unsigned)(((G + X - 1) / X) * X));
 }
 
 bool aligned_rows(const void *p, int W, size_t elem) {   // every 8-pixel block row starts on 8 B (u8) / 16 B (f32)
@@ -253,8 +260,8 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
                      double alpha, const Workspace &ws, bool fused, const Ctx &cx, bool ysum2_is_zero = false) {
     hipStream_t s = cx.s;
     if (fused && !ysum2_is_zero) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
-    const Geom g = make_geom(H, W, ws, n);
-    const dim3 grid = xcd_grid(g.nblk, n);
+    const Geom g = make_geom(H, W, ws, n, cx.xcds);
+    const dim3 grid = xcd_grid(g.nblk, n, cx.xcds);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
     MarkArgs m;
     m.rec = ws.rec;
@@ -469,7 +476,7 @@ int launch_analyze_yuv420(const uint8_t *frames, int layout, int n, int H, int W
     HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, cx.s));
     const PGeom g = make_pgeom(layout, H, W, ws.plane);
     const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);     // 2-D grid: the planar kernels gain nothing from the XCD order
-    ScopedTiming timing(KIND_PLANAR, cx);
+    ScopedTiming timing(KIND_PLANAR_ANALYZE, cx);
     if (layout == OFMK_YUV_I420) OFMK_TIMED_LAUNCH(timing, analyze_yuv420_kernel<FMT_I420>, grid, dim3(kThreads), 0, cx.s, frames, g, ws.rec, ws.ysum, zero_counts, L);
     else OFMK_TIMED_LAUNCH(timing, analyze_yuv420_kernel<FMT_NV12>, grid, dim3(kThreads), 0, cx.s, frames, g, ws.rec, ws.ysum, zero_counts, L);
     HIP_TRY(hipGetLastError());
@@ -488,7 +495,7 @@ int launch_mark_yuv420(const uint8_t *in, uint8_t *out, int layout, int n, int H
     m.n_wm = n_wm;
     m.N = (int)((long long)H * W / 64);
     m.alpha = alpha;
-    ScopedTiming timing(KIND_PLANAR, cx);
+    ScopedTiming timing(KIND_PLANAR_MARK, cx);
     if (layout == OFMK_YUV_I420) {
         if (fused) OFMK_TIMED_LAUNCH(timing, (mark_yuv420_kernel<FMT_I420, true>), grid, dim3(kThreads), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2);
         else OFMK_TIMED_LAUNCH(timing, (mark_yuv420_kernel<FMT_I420, false>), grid, dim3(kThreads), 0, cx.s, in, out, g, m, ws.rec, ws.ysum2);
@@ -768,18 +775,20 @@ int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, i
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.N = (int)((long long)H * W / 64); a.L = 1;
+    const Ctx cx = make_ctx(stream, opts);
+    ScopedTiming timing(KIND_SVD, cx);                    // the plugin path's launches are timed like every other
     if (blk == 8) {
         const Geom8 g8 = make_geom8(H, W);
         if (g8.ntile > 0)
-            hipLaunchKernelGGL((svd8_yuv32f_kernel<SVD_EMBED>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0,
-                               static_cast<hipStream_t>(stream), yuv, g8, to_args8(a, H, W));
+            OFMK_TIMED_LAUNCH(timing, (svd8_yuv32f_kernel<SVD_EMBED>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0,
+                              cx.s, yuv, g8, to_args8(a, H, W));
         HIP_TRY(hipGetLastError());
         return OFMK_OK;
     }
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
-    hipLaunchKernelGGL((svd_yuv32f_kernel<SVD_EMBED>), block_grid(g, n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), yuv, g, a);
+    OFMK_TIMED_LAUNCH(timing, (svd_yuv32f_kernel<SVD_EMBED>), block_grid(g, n), dim3(kThreads), 0, cx.s, yuv, g, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
@@ -796,14 +805,16 @@ int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, true))) return rc;
     a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = 1;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ctx cx = make_ctx(stream, opts);
+    hipStream_t s = cx.s;
     if (blk == 8) {                                       // bits: [n][H*W/256] (dwt_dct_svd_decoder.py:14)
         const Geom8 g8 = make_geom8(H, W);
         const Svd8Args a8 = to_args8(a, H, W);
         if (a8.N8 > g8.ntile || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a8.N8, s));
         if (!(a.scales[1] > 0.f) || g8.ntile == 0) return OFMK_OK;
-        hipLaunchKernelGGL((svd8_yuv32f_kernel<SVD_DETECT>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0, s,
-                           const_cast<float *>(yuv), g8, a8);
+        ScopedTiming timing(KIND_SVD, cx);
+        OFMK_TIMED_LAUNCH(timing, (svd8_yuv32f_kernel<SVD_DETECT>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0, s,
+                          const_cast<float *>(yuv), g8, a8);
         HIP_TRY(hipGetLastError());
         return OFMK_OK;
     }
@@ -812,7 +823,8 @@ int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *
     const Geom g = make_geom(H, W, none);
     if (a.N > g.nblk || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
     if (!(a.scales[1] > 0.f)) return OFMK_OK;
-    hipLaunchKernelGGL((svd_yuv32f_kernel<SVD_DETECT>), block_grid(g, n), dim3(kThreads), 0, s, const_cast<float *>(yuv), g, a);
+    ScopedTiming timing(KIND_SVD, cx);
+    OFMK_TIMED_LAUNCH(timing, (svd_yuv32f_kernel<SVD_DETECT>), block_grid(g, n), dim3(kThreads), 0, s, const_cast<float *>(yuv), g, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
@@ -933,6 +945,14 @@ int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int
         if (layout == OFMK_YUV_I420) hipLaunchKernelGGL(rgb8_to_yuv420_kernel<FMT_I420>, grid, dim3(kThreads), 0, s, pi, po, g);
         else hipLaunchKernelGGL(rgb8_to_yuv420_kernel<FMT_NV12>, grid, dim3(kThreads), 0, s, pi, po, g);
     }
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int ofmk_probe_xcc(int32_t *xcc_of_workgroup, int n_workgroups, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
+    if (!xcc_of_workgroup || n_workgroups < 1 || n_workgroups > (1 << 20)) return fail(OFMK_E_ARG, "probe needs an output array and 1..2^20 workgroups%s");
+    hipLaunchKernelGGL(probe_xcc_kernel, dim3((unsigned)n_workgroups), dim3(64), 0, static_cast<hipStream_t>(stream), xcc_of_workgroup, n_workgroups);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }

@@ -12,20 +12,21 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liboffmark_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Opts(C.Structure):
     """ofmk_opts: per-call options (flags, optional timing object).  None / NULL = defaults.
     An Opts made by Timing.opts() keeps its Timing alive (``_timing``) and is invalidated by Timing.close(): its
     pointer is nulled, so an engine that still holds it simply launches without events instead of touching freed memory."""
-    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_uint32), ("timing", C.c_void_p)]
+    _fields_ = [("flags", C.c_uint32), ("xcds", C.c_uint32), ("timing", C.c_void_p)]
     _timing = None
 
 
 F_SEPARATE_DETECT = 1
+F_LINEAR_TILES = 2          # tile order of the frame-writing DCT kernel: workgroup index instead of the XCD-aware order
 YUV_I420, YUV_NV12 = 0, 1
-TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar")
+TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar_analyze", "planar_mark")
 
 _vp, _i32, _f64, _sz, _u32 = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_uint
 _op = C.POINTER(Opts)
@@ -58,6 +59,7 @@ SIGNATURES = {
                                         _sz, _vp, _op]),
     "ofmk_yuv420_to_rgb8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _op]),
     "ofmk_rgb8_to_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _op]),
+    "ofmk_probe_xcc": (_i32, [_vp, _i32, _vp, _op]),
     "ofmk_hbm_copy": (_i32, [_vp, _vp, _sz, _vp]),
     "ofmk_hbm_read": (_i32, [_vp, _sz, _vp, _vp]),
     "ofmk_timing_create": (_i32, [_i32, _u32, C.POINTER(_vp)]),

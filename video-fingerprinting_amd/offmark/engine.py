@@ -23,18 +23,72 @@ def default_chunk_frames(H: int, W: int, bytes_per_sample: int = 1) -> int:
     return max(1, _CACHE_BUDGET_BYTES // (H * W * 3 * bytes_per_sample))
 
 
+def balanced_chunk(n: int, cap: int) -> int:
+    """Frames per chunk when n frames are processed in chunks of at most ``cap``: the fewest chunks, all (nearly) equal --
+    384 frames under a cap of 345 run as 192 + 192, not 345 + 39 (a short tail chunk pays a whole launch's ramp and tail
+    for a ninth of the work: VERDICT r3, config 4 lost ~10 % to it)."""
+    cap = max(1, cap)
+    if n <= cap:
+        return max(1, n)
+    k = -(-n // cap)
+    return -(-n // k)
+
+
+# ---- tile order of the frame-writing DCT kernel (include/offmark_hip.h: OFMK_F_LINEAR_TILES) -----------------------------
+# Which order is faster differs from box to box by a few per cent (the builder's boxes: XCD-aware -1.4 .. -2.6 %; the driver's:
+# +5 % between BENCH_r02 and BENCH_r03), so it is MEASURED once per device and process: the first batch of at least
+# _CALIBRATE_MIN_BYTES of frames an engine marks is first run a few times in both orders, interleaved, on the caller's own
+# buffers, and the faster one is kept for every engine on that device (results are identical bit for bit either way).
+# OFFMARK_TILE_ORDER = auto (default) | xcd | linear overrides; DctEngine(tile_order=...) overrides that.
+_TILE_ORDER = {}              # device index -> dict(order=..., xcd_ms=..., linear_ms=..., ...)
+_XCC_DEAL = {}                # device index -> probe_xcc_deal() result
+_CALIBRATE_MIN_BYTES = 192 << 20
+
+
+def probe_xcc_deal(device=None, workgroups: int = 4096) -> dict:
+    """Ask the hardware which XCD each workgroup of a linear grid runs on (HW_REG_XCC_ID, ofmk_probe_xcc).
+    Returns xcds (distinct ids seen), round_robin (True when workgroups L and L + xcds always share an XCD -- all the
+    XCD-aware tile order assumes), ids_by_residue (the id of residue class L % xcds, in order: WHICH XCD gets workgroup 0
+    is not fixed) and the fraction of workgroups that fit the round-robin pattern."""
+    torch = _hip.require_gpu()
+    lib = _hip.load()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _XCC_DEAL:
+        return _XCC_DEAL[key]
+    with torch.cuda.device(dev):
+        ids = torch.full((workgroups,), -1, dtype=torch.int32, device=dev)
+        _hip.check(lib.ofmk_probe_xcc(ids.data_ptr(), workgroups, _hip.current_stream(), None))
+        got = ids.cpu().numpy()
+    seen = sorted(int(v) for v in np.unique(got))
+    X = len(seen)
+    by_res = [int(np.bincount(got[r::X], minlength=16).argmax()) for r in range(X)]
+    fit = float(np.mean(got == np.asarray(by_res)[np.arange(workgroups) % X]))
+    out = dict(xcds=X, round_robin=bool(fit == 1.0 and len(set(by_res)) == X), ids_by_residue=by_res,
+               round_robin_fraction=round(fit, 4), workgroups=workgroups)
+    _XCC_DEAL[key] = out
+    return out
+
+
 class DctEngine:
     """Enqueue embed / detect for batches of interleaved u8 frames [n, H, W, 3] on one GPU."""
 
-    def __init__(self, device=None, chunk_frames: int | None = None, opts=None):
+    def __init__(self, device=None, chunk_frames: int | None = None, opts=None, tile_order: str | None = None):
         """opts: an _hip.Opts applied to every batch call of this engine (flags, timing object); engines share
-        no state, so two engines on two streams may be driven from two threads."""
+        no state, so two engines on two streams may be driven from two threads.
+        tile_order: "xcd" | "linear" | "auto" (default: $OFFMARK_TILE_ORDER, else "auto" = calibrate once per device on the
+        first large batch, see calibrate_tile_order).  A pure scheduling choice: results do not depend on it."""
         self.opts = opts
         self.torch = _hip.require_gpu()
         self.lib = _hip.load()
         self.device = self.torch.device("cuda", self.torch.cuda.current_device()) if device is None \
             else self.torch.device(device)
         self.chunk_frames = chunk_frames
+        order = tile_order or os.environ.get("OFFMARK_TILE_ORDER", "auto")
+        if order not in ("auto", "xcd", "linear"):
+            raise ValueError(f"tile_order must be 'auto', 'xcd' or 'linear', not {order!r}")
+        self._order_mode = order
+        self._opts_cache = None
         # range-check device-resident row maps too (costs a host synchronisation per call, so off by default; the kernels
         # clamp every entry into [0, n_wm) either way -- include/offmark_hip.h)
         self.debug_checks = os.environ.get("OFFMARK_DEBUG_CHECKS", "0") not in ("", "0")
@@ -54,8 +108,99 @@ class DctEngine:
         return ws
 
     def _chunk(self, n, H, W, bytes_per_sample=1):
-        c = self.chunk_frames or default_chunk_frames(H, W, bytes_per_sample)
-        return max(1, min(n, c))
+        """Frames per internal chunk: equal chunks under the cap (chunk_frames or the byte budget)."""
+        return balanced_chunk(n, self.chunk_frames or default_chunk_frames(H, W, bytes_per_sample))
+
+    # -- tile order ------------------------------------------------------------------------------
+    @property
+    def device_key(self):
+        return self.device.index if self.device.index is not None else self.torch.cuda.current_device()
+
+    @property
+    def tile_order(self) -> str:
+        """The order in use: this engine's fixed choice, else the device's calibrated one, else "xcd" (not yet calibrated)."""
+        if self._order_mode != "auto":
+            return self._order_mode
+        return _TILE_ORDER.get(self.device_key, {}).get("order", "xcd")
+
+    @property
+    def tile_order_info(self) -> dict:
+        return dict(_TILE_ORDER.get(self.device_key, {}), mode=self._order_mode, in_use=self.tile_order)
+
+    def _o(self):
+        """ctypes argument for this call's ofmk_opts: the engine's opts (flags, timing) plus the tile order."""
+        base = self.opts
+        flags = base.flags if base is not None else 0
+        xcds = base.xcds if base is not None else 0
+        if not xcds:                                          # a device whose probe counted other than 8 XCDs (partition modes)
+            xcds = _TILE_ORDER.get(self.device_key, {}).get("xcds", 0)
+            xcds = 0 if xcds == 8 else xcds
+        if self.tile_order == "linear":
+            flags |= _hip.F_LINEAR_TILES
+        if base is not None and flags == base.flags and xcds == base.xcds:
+            return _hip.opts_ref(base)
+        if flags == 0 and xcds == 0 and base is None:
+            return None
+        o = _hip.Opts(flags, xcds, base.timing if base is not None else None)
+        self._opts_cache = o                                  # alive until the next call
+        return _hip.opts_ref(o)
+
+    def calibrate_tile_order(self, frames, out=None, pairs: int = 6, force: bool = False) -> dict:
+        """Time the fused mark+verify kernel on ``frames`` (CUDA uint8 [n, H, W, 3]) in both tile orders -- ``pairs``
+        launches each, interleaved A B B A ..., durations from the dispatches' own timestamps -- and keep the faster
+        order for every engine on this device.  Synchronises; ``out`` (a buffer the marked frames may be written to;
+        default: a temporary one) must not alias ``frames``.  Not run under stream capture."""
+        t = self.torch
+        key = self.device_key
+        if key in _TILE_ORDER and not force:
+            return _TILE_ORDER[key]
+        n, H, W = self._check_frames(frames, t.uint8)
+        m = self._chunk(n, H, W)
+        src = frames[:m]
+        if out is None or out.data_ptr() == frames.data_ptr():
+            dst = t.empty_like(src)
+        else:
+            dst = self._out(out, frames)[:m]
+        deal = probe_xcc_deal(self.device)
+        ws = self.workspace(H, W, m)
+        wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
+        wm[0, ::2] = 1
+        stream = _hip.current_stream()
+        kinds = (1 << _hip.TIMING_KINDS.index("mark_fused"))
+        sums = {"xcd": [], "linear": []}
+        timing = _hip.Timing(4, kinds)
+        try:
+            def one(order, timed):
+                _hip.check(self.lib.ofmk_stage_analyze_rgb8(src.data_ptr(), m, H, W, ws.data_ptr(), ws.numel(), stream, None))
+                o = _hip.Opts(_hip.F_LINEAR_TILES if order == "linear" else 0, deal["xcds"] if deal["round_robin"] else 0,
+                              timing.handle if timed else None)
+                _hip.check(self.lib.ofmk_stage_mark_rgb8(src.data_ptr(), dst.data_ptr(), m, H, W, wm.data_ptr(), 20.0, 1,
+                                                         ws.data_ptr(), ws.numel(), stream, _hip.opts_ref(o)))
+                if timed:
+                    t.cuda.current_stream().synchronize()
+                    got = timing.collect()["mark_fused"]
+                    if got["launches"]:
+                        sums[order].append(got["ms_total"] / got["launches"])
+            for order in ("xcd", "linear", "xcd", "linear"):
+                one(order, False)
+            for i in range(pairs):
+                for order in (("xcd", "linear") if i % 2 == 0 else ("linear", "xcd")):
+                    one(order, True)
+        finally:
+            timing.close()
+        med = {k: float(np.median(v)) if v else float("inf") for k, v in sums.items()}
+        order = "linear" if (med["linear"] < med["xcd"] or not deal["round_robin"]) else "xcd"
+        info = dict(order=order, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5), launches_each=pairs,
+                    frames=int(m), height=H, width=W, xcds=deal["xcds"], round_robin=deal["round_robin"])
+        _TILE_ORDER[key] = info
+        return info
+
+    def _maybe_calibrate(self, frames, out):
+        if self._order_mode != "auto" or self.device_key in _TILE_ORDER:
+            return
+        if frames.numel() < _CALIBRATE_MIN_BYTES or self.torch.cuda.is_current_stream_capturing():
+            return
+        self.calibrate_tile_order(frames, out)
 
     def _check_frames(self, frames, dtype):
         t = self.torch
@@ -122,11 +267,12 @@ class DctEngine:
         wm = self._wm(wm, N)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
+        self._maybe_calibrate(frames, out)
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
                                             _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
-                                            _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                            _hip.current_stream(), self._o()))
         return out
 
     def detect(self, frames, L, alpha=20, want_bits=False):
@@ -140,7 +286,7 @@ class DctEngine:
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_detect_rgb8(frames.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
                                              _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(),
-                                             _hip.opts_ref(self.opts)))
+                                             self._o()))
         return counts, bits
 
     def detect_soft(self, frames, L, alpha=20):
@@ -151,7 +297,7 @@ class DctEngine:
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_detect_soft_rgb8(frames.data_ptr(), n, H, W, int(L), float(alpha), soft.data_ptr(), cf,
-                                                  ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                  ws.data_ptr(), ws.numel(), _hip.current_stream(), self._o()))
         return soft
 
     def embed_detect(self, frames, wm, L, alpha=20, wm_row=None, out=None, want_bits=False):
@@ -164,12 +310,13 @@ class DctEngine:
         out = self._out(out, frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
+        self._maybe_calibrate(frames, out)
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                    wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
                                                    counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
-                                                   _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                   _hip.current_stream(), self._o()))
         return out, counts, bits
 
     def payloads(self, counts, n_bits: int, perm, out=None):
@@ -181,7 +328,7 @@ class DctEngine:
         if out is None:
             out = t.empty((n, L), dtype=t.uint8, device=self.device)
         _hip.check(self.lib.ofmk_payloads_from_counts(counts.data_ptr(), n, L, int(n_bits), perm.data_ptr(),
-                                                      out.data_ptr(), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                      out.data_ptr(), _hip.current_stream(), self._o()))
         return out
 
     # -- planar 8-bit YUV 4:2:0 in and out (what a decoder hands over / an encoder takes) -----------
@@ -208,7 +355,7 @@ class DctEngine:
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_embed_yuv420(planes.data_ptr(), out.data_ptr(), self._layout(layout), n, H, W, wm.data_ptr(),
                                               wm.shape[0], _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
-                                              _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                              _hip.current_stream(), self._o()))
         return out
 
     def detect_yuv420(self, planes, H, W, L, alpha=20, want_bits=False, layout="i420"):
@@ -220,7 +367,7 @@ class DctEngine:
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_detect_yuv420(planes.data_ptr(), self._layout(layout), n, H, W, int(L), float(alpha),
                                                counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
-                                               _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                               _hip.current_stream(), self._o()))
         return counts, bits
 
     def embed_detect_yuv420(self, planes, H, W, wm, L, alpha=20, wm_row=None, out=None, want_bits=False, layout="i420"):
@@ -237,7 +384,7 @@ class DctEngine:
         _hip.check(self.lib.ofmk_embed_detect_yuv420(planes.data_ptr(), out.data_ptr(), self._layout(layout), n, H, W,
                                                      wm.data_ptr(), wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
                                                      counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
-                                                     _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                     _hip.current_stream(), self._o()))
         return out, counts, bits
 
     def yuv420_to_rgb(self, planes, H, W, layout="i420", out=None):
@@ -245,7 +392,7 @@ class DctEngine:
         n = self._check_planar(planes, H, W)
         rgb = self._out(out, planes, (n, H, W, 3))
         _hip.check(self.lib.ofmk_yuv420_to_rgb8(planes.data_ptr(), rgb.data_ptr(), self._layout(layout), n, H, W,
-                                                _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                _hip.current_stream(), self._o()))
         return rgb
 
     def rgb_to_yuv420(self, frames, layout="i420", out=None):
@@ -255,7 +402,7 @@ class DctEngine:
             raise ValueError("planar 4:2:0 frames need H and W to be multiples of 8")
         planes = self._out(out, frames, (n, H * W * 3 // 2))
         _hip.check(self.lib.ofmk_rgb8_to_yuv420(frames.data_ptr(), planes.data_ptr(), self._layout(layout), n, H, W,
-                                                _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                _hip.current_stream(), self._o()))
         return planes
 
     # -- float32 YUV path (the literal encode(yuv)/decode(yuv) plugin boundary) ------------------
@@ -267,7 +414,7 @@ class DctEngine:
         cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], _hip.ptr(rows),
-                                               float(alpha), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                               float(alpha), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(), self._o()))
         return yuv
 
     def decode_yuv(self, yuv, L=1, alpha=20, want_bits=True):
@@ -279,7 +426,7 @@ class DctEngine:
         cf = self._chunk(n, H, W, bytes_per_sample=4)
         ws = self.workspace(H, W, cf)
         _hip.check(self.lib.ofmk_decode_yuv32f(yuv.data_ptr(), n, H, W, int(L), float(alpha), counts.data_ptr(),
-                                               _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                               _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), _hip.current_stream(), self._o()))
         return counts, bits
 
     # -- DwtDctSvd codec (one pass, no workspace) ---------------------------------------------------
@@ -296,7 +443,7 @@ class DctEngine:
         out = self._out(out, frames)
         _hip.check(self.lib.ofmk_svd_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
                                                 _hip.ptr(rows), _hip.scales3(scale, scales), int(blk), _hip.current_stream(),
-                                                _hip.opts_ref(self.opts)))
+                                                self._o()))
         return out
 
     def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None, blk=4):
@@ -305,7 +452,7 @@ class DctEngine:
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), _hip.scales3(scale, scales), int(blk), counts.data_ptr(),
-                                                 _hip.ptr(bits), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                 _hip.ptr(bits), _hip.current_stream(), self._o()))
         return counts, bits
 
     def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None, blk=4):
@@ -319,7 +466,7 @@ class DctEngine:
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                        wm.shape[0], _hip.ptr(rows), _hip.scales3(scale, scales), int(blk), int(L),
                                                        counts.data_ptr(), _hip.ptr(bits), _hip.current_stream(),
-                                                       _hip.opts_ref(self.opts)))
+                                                       self._o()))
         return out, counts, bits
 
     def svd_encode_yuv(self, yuv, wm, scale=15, scales=None, blk=4):
@@ -327,7 +474,7 @@ class DctEngine:
         n, H, W = self._check_frames(yuv, t.float32)
         wm = self._wm(wm, H * W // 64)
         _hip.check(self.lib.ofmk_svd_encode_yuv32f(yuv.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0], None,
-                                                   _hip.scales3(scale, scales), int(blk), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                   _hip.scales3(scale, scales), int(blk), _hip.current_stream(), self._o()))
         return yuv
 
     def svd_decode_yuv(self, yuv, scale=15, scales=None, blk=4):
@@ -335,7 +482,7 @@ class DctEngine:
         n, H, W = self._check_frames(yuv, t.float32)
         bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device)
         _hip.check(self.lib.ofmk_svd_decode_yuv32f(yuv.data_ptr(), n, H, W, _hip.scales3(scale, scales), int(blk), bits.data_ptr(),
-                                                   _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                                   _hip.current_stream(), self._o()))
         return bits
 
     # -- parity planes ----------------------------------------------------------------------------
@@ -354,7 +501,7 @@ class DctEngine:
                                               _hip.ptr(wmt), ydc.data_ptr(), lum.data_ptr(), tex.data_ptr(),
                                               step.data_ptr(), c21_pre.data_ptr(),
                                               c21_post.data_ptr() if wmt is not None else None,
-                                              ws.data_ptr(), ws.numel(), _hip.current_stream(), _hip.opts_ref(self.opts)))
+                                              ws.data_ptr(), ws.numel(), _hip.current_stream(), self._o()))
         out = dict(y_dc=ydc, lum=lum, tex=tex, step=step, c21_pre=c21_pre)
         if wmt is not None:
             out["c21_post"] = c21_post

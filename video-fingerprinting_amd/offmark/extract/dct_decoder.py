@@ -40,6 +40,10 @@ class DctDecoder:
         return self._planes(lum)["tex"]
 
     # -- batch fast path ---------------------------------------------------------------------------
+    def bits_per_frame(self, height, width):
+        """Length of decode()'s bit vector for a frame of this size (dct_decoder.py:16): what the degenerator's means divide by."""
+        return height * width // 64
+
     def decode_frames_u8(self, frames, payload_len, want_bits=False):
         """frames: CUDA uint8 [n, H, W, 3] -> (counts int32 [n, L] on device, bits or None)."""
         return self.engine.detect(frames, payload_len, alpha=self.alpha, want_bits=want_bits)

@@ -31,6 +31,11 @@ class DwtDctSvdDecoder:
         self.block_num = bits.shape[1]
         return bits.cpu().numpy().astype(np.float64).reshape(1, -1)
 
+    def bits_per_frame(self, height, width):
+        """Length of decode()'s bit vector (dwt_dct_svd_decoder.py:14: row*col//4//blk**2): H*W//64 for blk = 4, H*W//256
+        for blk = 8.  The degenerator's means divide by the slice lengths of a vector of THIS length."""
+        return DctEngine.svd_bits_per_frame(height, width, self.blk)
+
     def decode_frames_u8(self, frames, payload_len, want_bits=False):
         """frames: CUDA uint8 [n, H, W, 3] -> (counts int32 [n, L] on device, bits or None)."""
         return self.engine.svd_detect(frames, payload_len, scales=self._scales, want_bits=want_bits, blk=self.blk)

@@ -115,7 +115,8 @@ def mark_segment_copies(encoder, decoder, frames, segment_of_frame, num_copies: 
         rows = np.array([index[(int(s), c)] for s in seg], dtype=np.int32)
         marked = encoder.encode_frames_u8(frames, wm_rows=torch.from_numpy(rows).to(frames.device), wm_table=table_dev)
         counts, _ = decoder.decode_frames_u8(marked, 8)
-        votes = vote_segments(deg.degenerate_counts(counts.cpu().numpy(), N), seg)
+        n_bits = decoder.bits_per_frame(H, W) if hasattr(decoder, "bits_per_frame") else N      # DwtDctSvd(blk=8): H*W//256
+        votes = vote_segments(deg.degenerate_counts(counts.cpu().numpy(), n_bits), seg)
         copies.append(marked)
         for s in segments:
             payload = payload_for_segment(s, c).tolist()

@@ -74,10 +74,12 @@ class Extractor:
             dev_out.copy_(counts)
 
         outer = self
+        # length of the decoder's bit vector: H*W//64 for the DCT codec and DwtDctSvd(blk=4), H*W//256 for DwtDctSvd(blk=8)
+        n_bits = dec.bits_per_frame(H, W) if hasattr(dec, "bits_per_frame") else H * W // 64
 
         class Sink:
             def deliver(self, counts):
-                for out in outer.degenerator.degenerate_counts(counts, H * W // 64):
+                for out in outer.degenerator.degenerate_counts(counts, n_bits):
                     outer.patterns.append(out)
                     logger.info(out)
 

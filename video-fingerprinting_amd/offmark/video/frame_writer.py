@@ -54,6 +54,8 @@ class ArrayFrameWriter(FrameWriter):
     def write_batch(self, frames):
         from .pipeline import host_copy
         frames = np.asarray(frames)
+        if frames.dtype != np.uint8:
+            frames = frames.astype(np.uint8)             # the reference's writer casts (frame_writer.py:41-44); ADVICE r3
         kept = np.empty(frames.shape, dtype=np.uint8)    # one copy: the caller may reuse its buffer
         host_copy(kept, frames)                          # (threaded: first touch of fresh pages is what costs)
         self.frames.extend(kept)
@@ -75,8 +77,14 @@ class ArrayFrameWriter(FrameWriter):
         self._pending -= n
 
     def array(self):
-        """The frames written through reserve/commit, as one [n, ...] view of the page-locked block."""
-        return self._block[: self._committed]
+        """Every frame written so far as one [n, ...] array: a view of the page-locked block when all of them went through
+        reserve/commit, else (the block was full or absent and frames arrived through write / write_batch) a stacked copy of
+        ``frames`` -- never a silently shortened stream."""
+        if self._block is not None and len(self.frames) == self._committed:
+            return self._block[: self._committed]
+        if not self.frames:
+            return np.empty((0,) + (tuple(self._block.shape[1:]) if self._block is not None else ()), dtype=np.uint8)
+        return np.stack(self.frames)
 
     def close(self):
         self.closed = True

@@ -152,25 +152,37 @@ class _ReadAhead(threading.Thread):
             if m:
                 host_copy(st[:m], self._check(np.asarray(b)))
         else:
+            # the reference's bare read(): one frame at a time (video/embedder.py:19-27).  A reader that fails in the middle
+            # of a batch has already delivered the frames before it: they are handed on (in order) and the exception
+            # follows them, exactly what the reference's loop would have processed before it died
             m = 0
-            while m < self.batch:
-                f = r.read()
-                if f is None:
-                    break
-                np.copyto(st[m], self._check(np.asarray(f)[None])[0])
-                m += 1
+            try:
+                while m < self.batch:
+                    f = r.read()
+                    if f is None:
+                        break
+                    np.copyto(st[m], self._check(np.asarray(f)[None])[0])
+                    m += 1
+            except BaseException as exc:
+                self._failed = exc
         if m == 0:
             self.free.put(st)
             return None
         return st[:m], st
 
+    _failed = None
+
     def run(self):
         try:
             while not self.stop.is_set():
                 item = self._next()
+                if item is None and self._failed is not None:
+                    raise self._failed
                 self.ready.put(item)
                 if item is None:
                     return
+                if self._failed is not None:              # the frames read before the failure went first
+                    raise self._failed
         except BaseException as exc:                      # handed to the caller's thread, which re-raises it
             self.ready.put(exc)
 
