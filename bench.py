@@ -513,28 +513,38 @@ def main():
         def add_lane(self, stream):
             j = self.j
             src = j.planes if planar else j.frames
-            lane = SimpleNamespace(eng=DctEngine(device=dev, chunk_frames=self.chunk, opts=opts_plain, tile_order=a.tile_order),
-                                   out=torch.empty_like(src) if j.mode == "embed_detect" else None, stream=stream,
-                                   pay=torch.empty((self.G, max(j.n, 0), L), dtype=torch.uint8, device=dev), graph=None)
+            mk_eng = lambda: DctEngine(device=dev, chunk_frames=self.chunk, opts=opts_plain, tile_order=a.tile_order)  # noqa: E731
+            mk_out = lambda: torch.empty_like(src) if j.mode == "embed_detect" else None  # noqa: E731
+            # a graphed group runs its steps on TWO branches (own engine = own workspace, own output buffer): consecutive steps
+            # of a small shard overlap, one step's tail and launch gaps under the other's kernels
+            two = self.use_graph and self.G >= 2 and j.n > 0
+            lane = SimpleNamespace(eng=mk_eng(), out=mk_out(), eng2=mk_eng() if two else None, out2=mk_out() if two else None, stream=stream,
+                                   pay=torch.empty((2, self.G, max(j.n, 0), L), dtype=torch.uint8, device=dev), graph=[None, None])
+            # pay[parity]: a group's payloads stay untouched while the side stream gathers and downloads them and the lane already
+            # runs its next group into the other half (one captured graph per half: a graph's addresses are fixed)
             self.lanes.append(lane)
             return lane
 
+        def engines(self):
+            return [e for lane in self.lanes for e in (lane.eng, lane.eng2) if e is not None]
+
         def set_opts(self, o):
-            for lane in self.lanes:
-                lane.eng.opts = o
+            for e in self.engines():
+                e.opts = o
 
         def set_order(self, order):
-            for lane in self.lanes:
-                lane.eng._order_mode = order
+            for e in self.engines():
+                e._order_mode = order
             self.drop_graphs()
 
         def drop_graphs(self):
             for lane in self.lanes:
-                lane.graph = None
+                lane.graph = [None, None]
 
-        def hot_path(self, lane, slot=0):
-            """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames -> lane.pay[slot]."""
-            j, e = self.j, lane.eng
+        def hot_path(self, lane, slot=0, par=0, branch=0):
+            """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames -> lane.pay[par, slot]."""
+            j = self.j
+            e, out = (lane.eng, lane.out) if branch == 0 else (lane.eng2, lane.out2)
             if j.n == 0:
                 return
             if j.mode == "detect":
@@ -543,12 +553,12 @@ def main():
                 else:
                     counts, _ = e.svd_detect(j.frames, L, scale=15, blk=a.blk)
             elif planar:
-                _, counts, _ = e.embed_detect_yuv420(j.planes, H, W, j.wm_dev, L, alpha=a.alpha, out=lane.out, layout=a.pixfmt)
+                _, counts, _ = e.embed_detect_yuv420(j.planes, H, W, j.wm_dev, L, alpha=a.alpha, out=out, layout=a.pixfmt)
             elif a.codec == "dct":
-                _, counts, _ = e.embed_detect(j.frames, j.wm_dev, L=L, alpha=a.alpha, wm_row=j.rows_dev, out=lane.out)
+                _, counts, _ = e.embed_detect(j.frames, j.wm_dev, L=L, alpha=a.alpha, wm_row=j.rows_dev, out=out)
             else:
-                _, counts, _ = e.svd_embed_detect(j.frames, j.wm_dev, L=L, scale=15, wm_row=j.rows_dev, out=lane.out, blk=a.blk)
-            e.payloads(counts, n_bits, perm_dev, out=lane.pay[slot])         # [n, L] uint8, on device
+                _, counts, _ = e.svd_embed_detect(j.frames, j.wm_dev, L=L, scale=15, wm_row=j.rows_dev, out=out, blk=a.blk)
+            e.payloads(counts, n_bits, perm_dev, out=lane.pay[par, slot])    # [n, L] uint8, on device
 
         def prepare(self):
             """One-time set-up, not a workload step: allocate the scratch for the chunk size in use, let the runtime load the code
@@ -556,25 +566,43 @@ def main():
             capture the G-step graph when asked.  Even --warmup 0 then times steady-state steps."""
             j = self.j
             for lane in self.lanes:
-                if j.n:
-                    lane.eng.workspace(H, W, lane.eng._chunk(j.n, H, W))
-                with torch.cuda.stream(lane.stream):
-                    self.hot_path(lane)
+                for b, e in enumerate((lane.eng, lane.eng2)):
+                    if e is None:
+                        continue
+                    if j.n:
+                        e.workspace(H, W, e._chunk(j.n, H, W))
+                    with torch.cuda.stream(lane.stream):
+                        self.hot_path(lane, branch=b)
             torch.cuda.synchronize()
+            if self.use_graph and j.n:
+                for lane in self.lanes:
+                    for par in (0, 1):
+                        self.capture(lane, par)
 
-        def capture(self, lane):
+        def capture(self, lane, par):
             """G steps of this lane as ONE hipGraph (C-ABI calls only enqueue work, so they capture)."""
-            cs = torch.cuda.Stream()
-            with torch.cuda.stream(cs):
+            cs, fork = torch.cuda.Stream(), torch.cuda.Stream()
+            two = lane.eng2 is not None
+
+            def body():
+                if two:
+                    fork.wait_stream(cs)                            # fork: odd steps on a second branch of the graph
                 for g_ in range(self.G):
-                    self.hot_path(lane, g_)
+                    if two and g_ % 2:
+                        with torch.cuda.stream(fork):
+                            self.hot_path(lane, g_, par, branch=1)
+                    else:
+                        self.hot_path(lane, g_, par)
+                if two:
+                    cs.wait_stream(fork)                            # join
+            with torch.cuda.stream(cs):
+                body()
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=cs):
-                    for g_ in range(self.G):
-                        self.hot_path(lane, g_)
+                    body()
             torch.cuda.synchronize()
-            lane.graph = graph
+            lane.graph[par] = graph
 
         def ids_for(self, size):
             """segment ids of the gathered rows of a group of `size` steps, rank-major [ranks, size, n_per_rank]: step g's segment s
@@ -595,23 +623,24 @@ def main():
             t_in = time.perf_counter()
             j = self.j
             lane = self.lanes[g % len(self.lanes)]
+            par = (g // len(self.lanes)) & 1
             timed_launches = lane.eng.opts is not None and lane.eng.opts.timing
             with torch.cuda.stream(lane.stream):
                 if self.use_graph and size == self.G and not timed_launches and j.n:
-                    if lane.graph is None:
-                        self.capture(lane)
-                    lane.graph.replay()
+                    if lane.graph[par] is None:
+                        self.capture(lane, par)
+                    lane.graph[par].replay()
                 else:
                     for g_ in range(size):
-                        self.hot_path(lane, g_)
+                        self.hot_path(lane, g_, par)
                 self.handoff[g & 1].record()
+            self.last = (lane, par)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.handoff[g & 1])
-                mine = lane.pay[:size].reshape(size * j.n, L)
-                mine.record_stream(self.side)
+                mine = lane.pay[par, :size].reshape(size * j.n, L)
                 if self.emulate:                                               # a device copy where the RCCL all-gather would be
                     buf = self.everyone[g & 1]
-                    buf[0, :size].copy_(lane.pay[:size])
+                    buf[0, :size].copy_(lane.pay[par, :size])
                     everyone = buf[:, :size].reshape(-1, L)
                 elif a.backend == "gloo" and grouped:                          # rehearsal: gloo gathers host tensors
                     everyone = gather_payloads(mine.cpu(), equal_shards=j.equal, force=grouped)
@@ -674,6 +703,11 @@ def main():
                 ok = ok and all(v is not None and v[0] is not None and np.array_equal(v[0], j.expected[s]) for s, v in vg.items())
                 if ok and cfg == 5:
                     ok = fp.identify_copies({s + 1: v for s, v in vg.items()}) == j.chosen
+                if not ok:                                  # say what failed (stderr; the line only carries the verdict)
+                    bad = {s: (None if v is None or v[0] is None else "".join(map(str, v[0])), "".join(map(str, j.expected[s])))
+                           for s, v in vg.items() if v is None or v[0] is None or not np.array_equal(v[0], j.expected[s])}
+                    sys.stderr.write(f"votes_ok: step {g_} of a group of {size}: {len(votes)} votes, wrong (got, want): {bad}\n")
+                    break
             return ok
 
     # steps per host iteration and graph capture: only shards too small to hide the host behind (module text)
@@ -706,7 +740,7 @@ def main():
     runner.prepare()
     if grouped:                                     # first collective on the side stream: RCCL sets its channels up here
         with torch.cuda.stream(runner.side):
-            p1 = lanes[0].pay[:1].reshape(-1, L)
+            p1 = lanes[0].pay[0, :1].reshape(-1, L)
             gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=job.equal, force=grouped)
         torch.cuda.synchronize()
     runner.set_opts(opts_timed)                             # every dominant-kernel launch of the timed steps carries its own event pair ...
@@ -716,6 +750,8 @@ def main():
             torch.cuda.synchronize()
             timing.collect()                                # rewind the event pool: the durations reported are the timed region's
     elapsed, votes, last_size = runner.timed(a.steps)
+    shipped_order = lanes[0].eng.tile_order                  # what the timed region ran with (later side measurements may calibrate)
+    shipped_info = lanes[0].eng.tile_order_info
     host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in runner.host_s.items()}
     runner.set_opts(opts_plain)
     kern = None
@@ -738,7 +774,7 @@ def main():
 
     # correctness of what was timed: every frame's payload, every segment's vote (and the leak's copy sequence)
     want_mine = job.expected_rows[job.first:job.first + n] if n else np.zeros((0, L), np.uint8)
-    got_mine = lanes[0].pay[0].cpu().numpy() if n else np.zeros((0, L), np.uint8)
+    got_mine = runner.last[0].pay[runner.last[1], 0].cpu().numpy() if n else np.zeros((0, L), np.uint8)
     ber = float((got_mine != want_mine).mean()) if n else 0.0
     votes_ok = runner.votes_ok(votes, last_size)
     payload_ok = bool((got_mine == want_mine).all())
@@ -762,8 +798,7 @@ def main():
     # ---- the fused mark kernel in BOTH tile orders, same K steps, interleaved in this process ----
     if a.codec == "dct" and mode == "embed_detect" and not planar and not a.separate_detect and not a.no_extras and n and not a.no_kernel_events:
         try:
-            shipped = lanes[0].eng.tile_order
-            info = lanes[0].eng.tile_order_info
+            shipped, info = shipped_order, shipped_info
             t_ab = _hip.Timing(2 * n_chunks * a.steps + 16, 1 << _hip.TIMING_KINDS.index("mark_fused"))
             runner.set_opts(t_ab.opts(flags))
             res = {"xcd": [], "linear": []}
@@ -1062,7 +1097,7 @@ def main():
         "config": {"workload": workload + f"{codec_name} {op}+vote (BASELINE.json {what})",
                    "codec": a.codec, "frames_per_gpu": n, "payload_bits": L, "alpha": a.alpha,
                    "chunk_frames": chunk, "chunks_per_step": n_chunks, "steps_per_host_iteration": G, "hipgraph": bool(use_graph),
-                   "tile_order": lanes[0].eng.tile_order if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
+                   "tile_order": shipped_order if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")
                    if a.codec == "dct" else ("stand-alone kernel" if mode == "detect" else "fused into the embed kernel"),
                    "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {sw} rank(s), one RCCL all-gather of payloads"},

@@ -657,6 +657,73 @@ def test_c_abi_calls_are_graph_capturable(eng):
     assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(pay, ref_pay)
 
 
+@pytest.mark.parametrize("codec", ["dct", "dct-detect", "svd4", "svd8", "planar"])
+def test_several_steps_in_one_graph_replay_like_eager(eng, codec):
+    """Three steps with three DIFFERENT batches captured into ONE hipGraph (bench.py's grouped steps: a 48-frame segment is too
+    little work to issue step by step), replayed four times: every replay of every step must equal the eager result bit for bit
+    -- marked frames, counts, payloads.  The steps share the engine's workspace (mean accumulators) and, through torch's
+    caching allocator, their counts buffer: exactly the shape that broke while the library zeroed buffers with hipMemsetAsync
+    (memset nodes of one buffer replay out of order on ROCm 7.2 from the second replay on: profiles/r4_graph_memset_order.txt;
+    the library now zero-fills with a kernel)."""
+    import torch
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.synthetic import synthetic_frames
+    H, W, n, G = 240, 320, 12, 3
+    N = H * W // 64
+    blk = 8 if codec == "svd8" else 4
+    nb = type(eng).svd_bits_per_frame(H, W, blk) if codec.startswith("svd") else N
+    wm = cuda(np.stack([orc.shuffle_generate(P8, (N,), 0), orc.shuffle_generate(1 - P8, (N,), 0)]).astype(np.uint8))
+    rows = [cuda(((np.arange(n) + g) % 2).astype(np.int32)) for g in range(G)]
+    perm = torch.as_tensor(DeShuffler(key=0).set_shape((8,)).payload_idx, dtype=torch.int32).cuda()
+    batches = [synthetic_frames(n, H, W, seed=900 + g) for g in range(G)]
+    if codec == "planar":
+        batches = [eng.rgb_to_yuv420(b) for b in batches]
+    if codec == "dct-detect":
+        batches = [eng.embed(b, wm, wm_row=rows[g]) for g, b in enumerate(batches)]
+    outs = [torch.zeros_like(b) for b in batches]
+    pays = torch.zeros((G, n, 8), dtype=torch.uint8, device="cuda")
+    keep = [None] * G
+
+    def one(g, keep_counts):
+        if codec == "dct":
+            _, c, _ = eng.embed_detect(batches[g], wm, L=8, wm_row=rows[g], out=outs[g])
+        elif codec == "dct-detect":
+            c, _ = eng.detect(batches[g], 8)
+        elif codec == "planar":
+            _, c, _ = eng.embed_detect_yuv420(batches[g], H, W, wm, 8, wm_row=rows[g], out=outs[g])
+        else:
+            _, c, _ = eng.svd_embed_detect(batches[g], wm, L=8, wm_row=rows[g], out=outs[g], blk=blk)
+        eng.payloads(c, nb, perm, out=pays[g])
+        if keep_counts:
+            keep[g] = c.clone()
+
+    for g in range(G):
+        one(g, True)
+    torch.cuda.synchronize()
+    ref = ([o.clone() for o in outs], pays.clone(), [k.clone() for k in keep])
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for g in range(G):
+            one(g, False)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for g in range(G):
+                one(g, False)                      # counts freed on return: the next step's allocation reuses the block
+    torch.cuda.synchronize()
+    for rep in range(4):
+        pays.zero_()
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(pays, ref[1]), (codec, rep, [bool(torch.equal(pays[g], ref[1][g])) for g in range(G)])
+        if codec != "dct-detect":
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref[0])), (codec, rep)
+    assert (pays[0].cpu().numpy() == np.where((np.arange(n) % 2)[:, None] == 0, P8, 1 - P8)).all()
+
+
 @pytest.mark.parametrize("codec", ["dct", "dwtdctsvd"])
 def test_mark_copies_sidecars_and_leak_identification(eng, codec, tmp_path):
     """mark_video_to_hls.py's flow (N copies per segment, verify, JSON sidecars) followed by
@@ -1053,7 +1120,7 @@ def test_bench_configs_run_at_one_gpu(config, extra):
     if config in (2, 3, 4):    # the fused mark kernel in both tile orders, interleaved in the same process
         mo = line["mark_order"]
         assert mo["xcd_ms"] > 0 and mo["linear_ms"] > 0 and mo["shipped"] in ("xcd", "linear") and mo["xcc_deal"]["xcds"] >= 1
-        assert line["config"]["tile_order"] == mo["shipped"]
+        assert line["config"]["tile_order"] == mo["shipped"]          # what the TIMED region used
     if config == 5:        # BASELINE configs[4]: the attack suite is reported next to the line; clean and noisy leaks must resolve
         assert line["config"]["codec"] == ("dwtdctsvd" if "dwtdctsvd" in extra else "dct")      # --codec is honoured
         assert ("svd" in line["roofline"]["kernel"]) == ("dwtdctsvd" in extra)

@@ -120,6 +120,19 @@ int fail(int code, const char *fmt, const char *detail = "") {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Zero-fill as a KERNEL, never hipMemsetAsync: every compute call must replay correctly from a captured hipGraph, and on ROCm 7.2
+// a graph that holds memset node -> kernel nodes -> memset node OF THE SAME BUFFER -> kernel nodes (two steps of a call sequence
+// sharing one counts / accumulator buffer) replays with the memsets out of order from the second replay on: measured with
+// tools/graph_memset_order.py (payloads right on the first replay, wrong on every later one; distinct buffers or this kernel: always
+// right); tests/test_gpu_parity.py::test_several_steps_in_one_graph_replay_like_eager pins it for both codecs.
+hipError_t launch_zero(void *p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const size_t vec = bytes / 16 + 1;
+    const unsigned grid = (unsigned)(vec < 256 * 2048 ? (vec + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, s, static_cast<uint8_t *>(p), bytes);
+    return hipGetLastError();
+}
+
 constexpr int kMaxChunk = 65535;   // frames per launch = gridDim.y
 
 struct Workspace {
@@ -221,7 +234,7 @@ int launch_analyze(const void *frames, int src, int n, int H, int W, const Works
     hipStream_t s = cx.s;
     // one fill for both accumulator arrays (they are adjacent): ysum for this pass, ysum2 for a fused mark+verify
     // kernel that may follow -- one dispatch less per step than zeroing ysum2 in front of the mark kernel
-    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, s));
+    HIP_TRY(launch_zero(ws.ysum, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws, n);
     const dim3 grid = xcd_grid(g.nblk, n);
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
@@ -259,7 +272,7 @@ int launch_finalize(FinArgs a, int n, const Ctx &cx) {
 int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
                      double alpha, const Workspace &ws, bool fused, const Ctx &cx, bool ysum2_is_zero = false) {
     hipStream_t s = cx.s;
-    if (fused && !ysum2_is_zero) HIP_TRY(hipMemsetAsync(ws.ysum2, 0, (size_t)n * kSlots * 8, s));
+    if (fused && !ysum2_is_zero) HIP_TRY(launch_zero(ws.ysum2, (size_t)n * kSlots * 8, s));
     const Geom g = make_geom(H, W, ws, n, cx.xcds);
     const dim3 grid = xcd_grid(g.nblk, n, cx.xcds);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
@@ -358,8 +371,8 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
     const bool al = aligned_rows(in, W, 1) && (mode == SVD_DETECT || aligned_rows(out, W, 1));
-    if (a.counts) HIP_TRY(hipMemsetAsync(a.counts, 0, (size_t)n * a.L * sizeof(int32_t), s));
-    if (a.bits && a.N > g.nblk) HIP_TRY(hipMemsetAsync(a.bits, 0, (size_t)n * a.N, s));   // entries past (H/8)(W/8) stay 0
+    if (a.counts) HIP_TRY(launch_zero(a.counts, (size_t)n * a.L * sizeof(int32_t), s));
+    if (a.bits && a.N > g.nblk) HIP_TRY(launch_zero(a.bits, (size_t)n * a.N, s));   // entries past (H/8)(W/8) stay 0
     for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
         const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
         const size_t fo = (size_t)f0 * g.frame_stride;
@@ -403,8 +416,8 @@ Geom8 make_geom8(int H, int W) {
 int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mode, Svd8Args a, const Ctx &cx) {
     hipStream_t s = cx.s;
     const Geom8 g = make_geom8(H, W);
-    if (a.counts) HIP_TRY(hipMemsetAsync(a.counts, 0, (size_t)n * a.L * sizeof(int32_t), s));
-    if (a.bits && a.N8 > g.ntile) HIP_TRY(hipMemsetAsync(a.bits, 0, (size_t)n * a.N8, s));    // entries past the tiles stay 0
+    if (a.counts) HIP_TRY(launch_zero(a.counts, (size_t)n * a.L * sizeof(int32_t), s));
+    if (a.bits && a.N8 > g.ntile) HIP_TRY(launch_zero(a.bits, (size_t)n * a.N8, s));    // entries past the tiles stay 0
     const int Hc = (((H / 4) * 2) / 8) * 16, Wc = g.wt * 16;                                    // the region the tiles cover
     if (g.ntile > 0) {
         const bool al = W % 8 == 0 && (uintptr_t)in % 8 == 0 && (mode == SVD_DETECT || (uintptr_t)out % 8 == 0);
@@ -473,7 +486,7 @@ PGeom make_pgeom(int layout, int H, int W, size_t plane) {
 
 int launch_analyze_yuv420(const uint8_t *frames, int layout, int n, int H, int W, const Workspace &ws, const Ctx &cx,
                           int32_t *zero_counts = nullptr, int L = 0) {
-    HIP_TRY(hipMemsetAsync(ws.ysum, 0, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, cx.s));
+    HIP_TRY(launch_zero(ws.ysum, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, cx.s));
     const PGeom g = make_pgeom(layout, H, W, ws.plane);
     const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);     // 2-D grid: the planar kernels gain nothing from the XCD order
     ScopedTiming timing(KIND_PLANAR_ANALYZE, cx);
@@ -597,7 +610,7 @@ int ofmk_detect_soft_rgb8(const uint8_t *in, int n, int H, int W, int L, double 
     Workspace ws;
     if ((rc = carve(workspace, workspace_bytes, H, W, chunk_frames, ws))) return rc;
     const Ctx cx = make_ctx(stream, opts);
-    HIP_TRY(hipMemsetAsync(soft, 0, (size_t)n * L * sizeof(long long), cx.s));
+    HIP_TRY(launch_zero(soft, (size_t)n * L * sizeof(long long), cx.s));
     const size_t fs = (size_t)H * W * 3;
     for (int f0 = 0; f0 < n; f0 += ws.frames) {
         const int cf = n - f0 < ws.frames ? n - f0 : ws.frames;
@@ -739,8 +752,8 @@ int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const do
     const size_t bits_per_frame = blk == 8 ? (size_t)((long long)H * W / 256) : (size_t)a.N;     // dwt_dct_svd_decoder.py:14
     if (!(a.scales[1] > 0.f)) {
         hipStream_t s = static_cast<hipStream_t>(stream);
-        if (counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * L * sizeof(int32_t), s));
-        if (bits) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * bits_per_frame, s));
+        if (counts) HIP_TRY(launch_zero(counts, (size_t)n * L * sizeof(int32_t), s));
+        if (bits) HIP_TRY(launch_zero(bits, (size_t)n * bits_per_frame, s));
         return OFMK_OK;
     }
     if (blk == 8) return launch_svd8_rgb8(in, nullptr, n, H, W, SVD_DETECT, to_args8(a, H, W), make_ctx(stream, opts));
@@ -810,7 +823,7 @@ int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *
     if (blk == 8) {                                       // bits: [n][H*W/256] (dwt_dct_svd_decoder.py:14)
         const Geom8 g8 = make_geom8(H, W);
         const Svd8Args a8 = to_args8(a, H, W);
-        if (a8.N8 > g8.ntile || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a8.N8, s));
+        if (a8.N8 > g8.ntile || !(a.scales[1] > 0.f)) HIP_TRY(launch_zero(bits, (size_t)n * a8.N8, s));
         if (!(a.scales[1] > 0.f) || g8.ntile == 0) return OFMK_OK;
         ScopedTiming timing(KIND_SVD, cx);
         OFMK_TIMED_LAUNCH(timing, (svd8_yuv32f_kernel<SVD_DETECT>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0, s,
@@ -821,7 +834,7 @@ int ofmk_svd_decode_yuv32f(const float *yuv, int n, int H, int W, const double *
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
-    if (a.N > g.nblk || !(a.scales[1] > 0.f)) HIP_TRY(hipMemsetAsync(bits, 0, (size_t)n * a.N, s));
+    if (a.N > g.nblk || !(a.scales[1] > 0.f)) HIP_TRY(launch_zero(bits, (size_t)n * a.N, s));
     if (!(a.scales[1] > 0.f)) return OFMK_OK;
     ScopedTiming timing(KIND_SVD, cx);
     OFMK_TIMED_LAUNCH(timing, (svd_yuv32f_kernel<SVD_DETECT>), block_grid(g, n), dim3(kThreads), 0, s, const_cast<float *>(yuv), g, a);

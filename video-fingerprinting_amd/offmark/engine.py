@@ -145,11 +145,17 @@ class DctEngine:
         self._opts_cache = o                                  # alive until the next call
         return _hip.opts_ref(o)
 
-    def calibrate_tile_order(self, frames, out=None, pairs: int = 6, force: bool = False) -> dict:
-        """Time the fused mark+verify kernel on ``frames`` (CUDA uint8 [n, H, W, 3]) in both tile orders -- ``pairs``
-        launches each, interleaved A B B A ..., durations from the dispatches' own timestamps -- and keep the faster
-        order for every engine on this device.  Synchronises; ``out`` (a buffer the marked frames may be written to;
-        default: a temporary one) must not alias ``frames``.  Not run under stream capture."""
+    def calibrate_tile_order(self, frames, out=None, min_ms: float = 250.0, max_ms: float = 800.0, force: bool = False) -> dict:
+        """Time the fused mark+verify kernel on ``frames`` (CUDA uint8 [n, H, W, 3]) in both tile orders and keep the faster
+        one for every engine on this device.  Launches go out in blocks of 4 interleaved pairs (A B B A A B B A, each mark
+        launch behind an analyze launch, as in a step; durations are the dispatches' own timestamps, one event pool per
+        order) and the device is kept busy from the first block to the last.  A device coming out of idle keeps speeding up
+        for the first few hundred milliseconds of load (DVFS: the same kernel took 0.775 ms in the first block, 0.688 ms 60 ms
+        later and 0.675 ms a second later, gpurun_out/r4a_bench_line_steps20_warmup5.json), and a choice made on that ramp
+        does not describe the state the work then runs in -- so blocks are added until at least ``min_ms`` of sustained load
+        have passed AND a block's mean duration is within 0.5 % of the previous block's (or ``max_ms`` have passed), and
+        the decision is taken on the last four blocks only.  Synchronises; ``out`` (a buffer the marked frames may be written
+        to; default: a temporary one) must not alias ``frames``.  Never run under stream capture."""
         t = self.torch
         key = self.device_key
         if key in _TILE_ORDER and not force:
@@ -162,36 +168,45 @@ class DctEngine:
         else:
             dst = self._out(out, frames)[:m]
         deal = probe_xcc_deal(self.device)
+        xcds = deal["xcds"] if deal["round_robin"] else 0
         ws = self.workspace(H, W, m)
         wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
         wm[0, ::2] = 1
         stream = _hip.current_stream()
         kinds = (1 << _hip.TIMING_KINDS.index("mark_fused"))
-        sums = {"xcd": [], "linear": []}
-        timing = _hip.Timing(4, kinds)
+        pools = {"xcd": _hip.Timing(8, kinds), "linear": _hip.Timing(8, kinds)}
+        opts = {"xcd": _hip.Opts(0, xcds, pools["xcd"].handle), "linear": _hip.Opts(_hip.F_LINEAR_TILES, xcds, pools["linear"].handle)}
+        blocks = []                                           # per block: {order: mean launch ms}
+        import time
+        t_start = time.perf_counter()
         try:
-            def one(order, timed):
+            def launch(order):
                 _hip.check(self.lib.ofmk_stage_analyze_rgb8(src.data_ptr(), m, H, W, ws.data_ptr(), ws.numel(), stream, None))
-                o = _hip.Opts(_hip.F_LINEAR_TILES if order == "linear" else 0, deal["xcds"] if deal["round_robin"] else 0,
-                              timing.handle if timed else None)
                 _hip.check(self.lib.ofmk_stage_mark_rgb8(src.data_ptr(), dst.data_ptr(), m, H, W, wm.data_ptr(), 20.0, 1,
-                                                         ws.data_ptr(), ws.numel(), stream, _hip.opts_ref(o)))
-                if timed:
-                    t.cuda.current_stream().synchronize()
-                    got = timing.collect()["mark_fused"]
-                    if got["launches"]:
-                        sums[order].append(got["ms_total"] / got["launches"])
-            for order in ("xcd", "linear", "xcd", "linear"):
-                one(order, False)
-            for i in range(pairs):
-                for order in (("xcd", "linear") if i % 2 == 0 else ("linear", "xcd")):
-                    one(order, True)
+                                                         ws.data_ptr(), ws.numel(), stream, _hip.opts_ref(opts[order])))
+            settled = False
+            while True:
+                for order in ("xcd", "linear", "linear", "xcd", "xcd", "linear", "linear", "xcd"):
+                    launch(order)
+                t.cuda.current_stream().synchronize()
+                got = {k: p.collect()["mark_fused"] for k, p in pools.items()}
+                blocks.append({k: v["ms_total"] / max(v["launches"], 1) for k, v in got.items()})
+                spent = 1e3 * (time.perf_counter() - t_start)
+                if len(blocks) >= 4 and spent >= min_ms:
+                    now, before = sum(blocks[-1].values()), sum(blocks[-2].values())
+                    settled = abs(now - before) <= 0.005 * before
+                    if settled or spent >= max_ms:
+                        break
         finally:
-            timing.close()
-        med = {k: float(np.median(v)) if v else float("inf") for k, v in sums.items()}
+            for p in pools.values():
+                p.close()
+        last = blocks[-4:]
+        med = {k: float(np.mean([b[k] for b in last])) for k in ("xcd", "linear")}
+        took_ms = 1e3 * (time.perf_counter() - t_start)
         order = "linear" if (med["linear"] < med["xcd"] or not deal["round_robin"]) else "xcd"
-        info = dict(order=order, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5), launches_each=pairs,
-                    frames=int(m), height=H, width=W, xcds=deal["xcds"], round_robin=deal["round_robin"])
+        info = dict(order=order, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5), blocks=len(blocks), launches_each=4 * len(blocks),
+                    first_block_ms=round(0.5 * sum(blocks[0].values()), 5), last_block_ms=round(0.5 * sum(blocks[-1].values()), 5),
+                    settled=bool(settled), calibration_ms=round(took_ms, 1), frames=int(m), height=H, width=W, xcds=deal["xcds"], round_robin=deal["round_robin"])
         _TILE_ORDER[key] = info
         return info
 
