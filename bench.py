@@ -711,19 +711,22 @@ def main():
             return ok
 
     # steps per host iteration and graph capture: only shards too small to hide the host behind (module text)
-    shard_bytes = n * H * W * 3
-    small_shard = 0 < shard_bytes < GRAPH_BELOW_BYTES
-    if a.group:
-        G = a.group
-    elif small_shard and job.equal:
-        G = max(1, min(16, -(-300 * 1080 * 1920 * 3 // max(shard_bytes, 1))))
-        while G > 1 and a.steps % G:            # a divisor of the step count: every group of the timed region is a full one
-            G -= 1
-    else:
-        G = 1
-    if not job.equal:
-        G = 1
-    use_graph = small_shard and not a.no_graph and a.streams == 1
+    def group_policy(j):
+        shard_bytes = j.n * H * W * 3
+        small = 0 < shard_bytes < GRAPH_BELOW_BYTES
+        if a.group:
+            g_ = a.group
+        elif small and j.equal:
+            g_ = max(1, min(16, -(-300 * 1080 * 1920 * 3 // max(shard_bytes, 1))))
+            while g_ > 1 and a.steps % g_:          # a divisor of the step count: every group of the timed region is a full one
+                g_ -= 1
+        else:
+            g_ = 1
+        if not j.equal:
+            g_ = 1
+        return g_, bool(small and not a.no_graph and a.streams == 1)
+
+    G, use_graph = group_policy(job)
     runner = Runner(job, n_lanes=a.streams, group=G, graph=use_graph, emulate=bool(emu))
     lanes = runner.lanes
     n_chunks = runner.n_chunks
@@ -754,10 +757,11 @@ def main():
     shipped_info = lanes[0].eng.tile_order_info
     host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in runner.host_s.items()}
     runner.set_opts(opts_plain)
-    kern = None
+    kern, series = None, []
     if not a.no_kernel_events:
         kern = {}
         if timing:
+            series = [m for m, k_ in timing.durations() if k_ == DOMINANT]
             kern = timing.collect()            # the dominant kernel's per-launch durations from the timed region itself
             timing.close()
         # every kernel kind, from a short pass of its own straight after (plain launches, a pair on every one)
@@ -827,7 +831,8 @@ def main():
 
     # ---- emulation of an M-rank job: the whole job on this GPU, for the predicted speed-up --------------------------
     if emu:
-        full = Runner(job_full, n_lanes=1, group=1, graph=False, emulate=False)
+        Gf, graph_f = group_policy(job_full)                  # the whole job as `bench.py --config C` runs it on one GPU
+        full = Runner(job_full, n_lanes=1, group=Gf, graph=graph_f, emulate=False)
         full.prepare()
         full.run(max(1, a.warmup))
         el_f, v_f, sz_f = full.timed(a.steps)
@@ -843,8 +848,9 @@ def main():
             predicted_frames_per_s=round(job.total_frames / (shard_ms * 1e-3), 1),
             note=f"rank 0 of {emu}: its shard's embed/detect/payloads, a device copy into the pre-filled [{emu}, G, n, L] buffer where the RCCL "
                  f"all-gather would be, download, vote over all {job.total_frames} payloads per step; predicted speed-up = "
-                 + ("M x " if job.scaling == "weak" else "") + "T(whole job on this GPU) / T(rank 0's step), best of two passes each.  Not modelled: the real "
-                 "all-gather's latency (side stream, off the critical path) and N processes sharing the host")
+                 + ("M x " if job.scaling == "weak" else "") + "T(whole job on this GPU, as `--gpus 1` runs it) / T(rank 0's step), best of two passes each; a graphed "
+                 "shard runs its steps on two graph branches, which a 300-frame single-stream step does not, so the ratio can exceed M.  Not modelled: "
+                 "the real all-gather's latency (side stream, off the critical path) and N processes sharing the host")
         del full
 
     # the same steps alternating between TWO HIP streams (own workspace and output buffer each): independent batches overlap, one
@@ -1072,6 +1078,12 @@ def main():
                         avg_launch_ms=per[dom]["avg_launch_ms"], launches=per[dom]["launches"],
                         frac_of_measured_copy=round(achieved / copy_gbps, 4),
                         frac_of_measured_read=round(achieved / read_gbps, 4))
+            if series:          # how the dominant kernel's duration moves through the timed region, launch by launch
+                q = max(1, len(series) // 4)
+                roof["launch_ms_through_the_timed_region"] = dict(
+                    first_quarter=round(float(np.mean(series[:q])), 5), last_quarter=round(float(np.mean(series[-q:])), 5),
+                    min=round(float(np.min(series)), 5), median=round(float(np.median(series)), 5), max=round(float(np.max(series)), 5),
+                    first_launches=[round(x, 4) for x in series[:6]])
 
     # 9 B/px per embed+detect frame with the DCT codec (4.5 on 4:2:0 planes); the DwtDctSvd codec has no frame-global
     # dependency and no separate detect read: 6 B/px; detect only: 3 B/px

@@ -245,6 +245,10 @@ int ofmk_probe_xcc(int32_t *xcc_of_workgroup, int n_workgroups, void *stream, co
 #define OFMK_TIMING_KINDS 7
 int ofmk_timing_create(int max_launches, unsigned kind_mask, ofmk_timing **out);
 int ofmk_timing_collect(ofmk_timing *t, double *ms_by_kind /*[OFMK_TIMING_KINDS]*/, int *launches_by_kind /*[OFMK_TIMING_KINDS]*/);
+/* The recorded launches one by one, in launch order (waits for their events; does NOT rewind the pool: call before collect):
+ * duration in ms and kernel kind of up to `cap` launches.  Returns the number written, or a negative error code.  bench.py
+ * uses it to show how the dominant kernel's duration moves through the timed region (clock ramp after idle). */
+int ofmk_timing_durations(ofmk_timing *t, float *ms_per_launch, int *kind_per_launch /* may be NULL */, int cap);
 void ofmk_timing_destroy(ofmk_timing *t);
 
 #ifdef __cplusplus

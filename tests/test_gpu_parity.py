@@ -1188,7 +1188,7 @@ def test_bench_emulates_rank_0_of_an_8_rank_job(config, extra):
     assert em["shard_frames"] == line["config"]["frames_per_gpu"] == (40 if config == 2 else 48)
     assert em["total_frames"] == 8 * em["shard_frames"]
     assert em["hipgraph"] and em["steps_per_host_iteration"] > 1 and 20 % em["steps_per_host_iteration"] == 0
-    assert 1.0 < em["predicted_speedup"] <= 8.5
+    assert 1.0 < em["predicted_speedup"] <= 10.0          # above 8 is possible: a graphed shard overlaps its steps on two branches
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1       # from the event pass after the graphed region
 
 

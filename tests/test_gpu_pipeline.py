@@ -167,6 +167,44 @@ def test_extractor_pipeline_equals_direct_detect(eng, codec):
         assert np.array_equal(ex.most_common()[0], P8)
 
 
+@pytest.mark.parametrize("L", [8, 5, 30])
+def test_extractor_and_copy_marking_with_blk8_divide_by_the_decoders_own_bit_count(eng, L):
+    """ADVICE r3: DwtDctSvdDecoder(blk=8) returns row*col//256 bits (dwt_dct_svd_decoder.py:14), a quarter of the DCT codec's
+    row*col//64, and DeShuffler's means are taken over the slices of THAT vector (de_shuffler.py:17-18).  The batched Extractor
+    (counts from the kernel + degenerate_counts) must give, frame by frame, what the reference's per-frame route gives:
+    decode(yuv) -> degenerate(bits) -- also when L does not divide the bit count (slice lengths differ) and when the frame has
+    fewer tiles than payload positions (64x96: 24 tiles < L = 30: empty slices are nan upstream, the payload decodes to zeros)."""
+    from offmark.degenerator.de_shuffler import DeShuffler
+    from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder
+    from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder
+    from offmark.generator.shuffler import Shuffler
+    from offmark.video.color import bgr2yuv
+    from offmark.video.extractor import Extractor
+    from offmark.video.frame_reader import ArrayFrameReader
+    from offmark import fingerprint as fp
+    n = 7
+    payload = np.random.default_rng(L).integers(0, 2, L)
+    payload[:2] = (0, 1)                                      # not constant: the mid-range threshold needs both values
+    enc, dec = DwtDctSvdEncoder(blk=8), DwtDctSvdDecoder(blk=8)
+    enc.read_wm(Shuffler(key=3).generate_wm(payload, enc.wm_capacity((H, W, 3))))
+    assert dec.bits_per_frame(H, W) == H * W // 256 == 24
+    marked = enc.encode_frames_u8(cuda(frames_rgb(n))).cpu().numpy()
+    deg = DeShuffler(key=3).set_shape(payload.shape)
+    with np.errstate(all="ignore"):
+        per_frame = np.stack([deg.degenerate(dec.decode(bgr2yuv(f.astype(np.float32)))) for f in marked])     # the reference's route
+    ex = Extractor(ArrayFrameReader(marked), dec, DeShuffler(key=3).set_shape(payload.shape), batch_frames=3)
+    ex.start()
+    assert np.array_equal(np.stack(ex.patterns), per_frame)
+    if L == 30:
+        assert not per_frame.any()                            # nan threshold upstream: nothing compares greater
+    elif L == 8:
+        assert np.array_equal(per_frame, np.tile(payload, (n, 1)))
+    if L == 8:      # mark_segment_copies verifies its copies with the same rule
+        copies, side = fp.mark_segment_copies(DwtDctSvdEncoder(blk=8), DwtDctSvdDecoder(blk=8), cuda(frames_rgb(8, 128, 192)),
+                                              np.repeat([1, 2], 4), num_copies=2)
+        assert side["failed_segments"] == [] and len(copies) == 2
+
+
 def test_empty_stream_and_failing_reader(eng):
     from offmark.degenerator.de_shuffler import DeShuffler
     from offmark.video.embedder import Embedder

@@ -432,10 +432,13 @@ int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int m
             gc.frames = cf;
             const dim3 grid = xcd_grid(g.ntile, cf);
             ScopedTiming timing(KIND_SVD, cx);
-#define OFMK_SVD8_LAUNCH(AL, MD) OFMK_TIMED_LAUNCH(timing, (svd8_rgb8_kernel<AL, MD>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, gc, b)
-            if (mode == SVD_DETECT) { if (al) OFMK_SVD8_LAUNCH(true, SVD_DETECT); else OFMK_SVD8_LAUNCH(false, SVD_DETECT); }
-            else if (mode == SVD_EMBED) { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED); else OFMK_SVD8_LAUNCH(false, SVD_EMBED); }
-            else { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED_VERIFY); else OFMK_SVD8_LAUNCH(false, SVD_EMBED_VERIFY); }
+#define OFMK_SVD8_LAUNCH(AL, MD, MU) OFMK_TIMED_LAUNCH(timing, (svd8_rgb8_kernel<AL, MD, MU>), grid, dim3(kThreads), 0, s, in + fo, out ? out + fo : nullptr, gc, b)
+            const bool multi = a.scales[0] > 0.f || a.scales[2] > 0.f || !(a.scales[1] > 0.f);      // anything but the default [0, s, 0]
+            if (mode == SVD_DETECT) { if (al) OFMK_SVD8_LAUNCH(true, SVD_DETECT, false); else OFMK_SVD8_LAUNCH(false, SVD_DETECT, false); }
+            else if (mode == SVD_EMBED && !multi) { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED, false); else OFMK_SVD8_LAUNCH(false, SVD_EMBED, false); }
+            else if (mode == SVD_EMBED) { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED, true); else OFMK_SVD8_LAUNCH(false, SVD_EMBED, true); }
+            else if (!multi) { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED_VERIFY, false); else OFMK_SVD8_LAUNCH(false, SVD_EMBED_VERIFY, false); }
+            else { if (al) OFMK_SVD8_LAUNCH(true, SVD_EMBED_VERIFY, true); else OFMK_SVD8_LAUNCH(false, SVD_EMBED_VERIFY, true); }
 #undef OFMK_SVD8_LAUNCH
         }
         HIP_TRY(hipGetLastError());
@@ -1016,6 +1019,23 @@ int ofmk_timing_collect(ofmk_timing *t, double *ms_by_kind, int *launches_by_kin
     t->used.store(0);
     if (rc) return rc;
     return OFMK_OK;
+}
+
+int ofmk_timing_durations(ofmk_timing *t, float *ms_per_launch, int *kind_per_launch, int cap) {
+    if (!t || !ms_per_launch || cap < 0) return fail(OFMK_E_ARG, "null pointer%s");
+    const int taken = t->used.load();
+    const int used = taken < t->cap ? taken : t->cap;
+    int n = 0;
+    for (int i = 0; i < used && n < cap; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(t->rec[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, t->rec[i].a, t->rec[i].b);
+        if (e != hipSuccess) { (void)hipGetLastError(); continue; }      // a pair whose launch failed was never recorded
+        ms_per_launch[n] = ms;
+        if (kind_per_launch) kind_per_launch[n] = t->rec[i].kind;
+        ++n;
+    }
+    return n;
 }
 
 void ofmk_timing_destroy(ofmk_timing *t) {

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ofmk_hbm_read": (_i32, [_vp, _sz, _vp, _vp]),
     "ofmk_timing_create": (_i32, [_i32, _u32, C.POINTER(_vp)]),
     "ofmk_timing_collect": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i32)]),
+    "ofmk_timing_durations": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(_i32), _i32]),
     "ofmk_timing_destroy": (None, [_vp]),
 }
 SYMBOLS = tuple(SIGNATURES)
@@ -124,6 +125,15 @@ class Timing:
         cnt = (_i32 * len(TIMING_KINDS))()
         check(self.lib.ofmk_timing_collect(self.handle, ms, cnt))
         return {k: dict(ms_total=ms[i], launches=cnt[i]) for i, k in enumerate(TIMING_KINDS)}
+
+    def durations(self, cap: int = 4096):
+        """[(ms, kind name)] of the recorded launches in launch order; does not rewind the pool (call before collect())."""
+        ms = (C.c_float * cap)()
+        kinds = (_i32 * cap)()
+        n = self.lib.ofmk_timing_durations(self.handle, ms, kinds, cap)
+        if n < 0:
+            check(n)
+        return [(float(ms[i]), TIMING_KINDS[kinds[i]] if 0 <= kinds[i] < len(TIMING_KINDS) else "?") for i in range(n)]
 
     def close(self):
         for ref in self._handed_out:                      # options still held elsewhere stop naming the pool
