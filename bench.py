@@ -565,6 +565,19 @@ def main():
             objects and the engine calibrate its tile order (one full-size pass, so that profiles only ever see full-size launches);
             capture the G-step graph when asked.  Even --warmup 0 then times steady-state steps."""
             j = self.j
+            # first use of the download path (side stream, page-locked landing buffers, events) BEFORE the device is brought to its
+            # operating state: in a kernel trace the first non-blocking D2H copy of the process held the host for milliseconds
+            # (6 ms under rocprofv3) right after the first step, and every idle gap of that size is followed by ~15 ms of slower
+            # launches (profiles/r4_idle_gap.txt) -- exactly where a short timed region sits
+            with torch.cuda.stream(self.side):
+                scratch = torch.zeros((1, L), dtype=torch.uint8, device=dev)
+                for h, ev in zip(self.host, self.ready):
+                    if h.shape[0]:
+                        h[:1].copy_(scratch, non_blocking=True)
+                    ev.record()
+                for ev in self.handoff:
+                    ev.record()
+            torch.cuda.synchronize()
             for lane in self.lanes:
                 for b, e in enumerate((lane.eng, lane.eng2)):
                     if e is None:
@@ -737,7 +750,12 @@ def main():
     # of their own after the timed region (`kernels`).  A graphed step carries no events (they ride on the dispatch, a graph
     # node has none): its dominant kernel is measured in that pass too.
     events_in_timed_region = not a.no_kernel_events and not use_graph
-    timing = _hip.Timing(2 * n_chunks * timed_steps + 16, 1 << _hip.TIMING_KINDS.index(DOMINANT)) if events_in_timed_region else None
+    # one pool for the warm-up AND the timed launches: nothing is collected (no host work, no extra idle time) between the warm-up
+    # and the contract's barrier + synchronize; the warm-up's entries are dropped when the durations are read.  Idle gaps matter on
+    # this device: after >= 5 ms of idleness the next launches run up to 25 % slower for ~10 ms, after ~1 ms a few per cent
+    # (tools/idle_gap_experiment.py, profiles/r4_idle_gap.txt)
+    warm_launches = n_chunks * a.warmup
+    timing = _hip.Timing(n_chunks * (timed_steps + a.warmup) + 16, 1 << _hip.TIMING_KINDS.index(DOMINANT)) if events_in_timed_region else None
     opts_timed = timing.opts(flags) if timing else opts_plain
 
     runner.prepare()
@@ -747,11 +765,15 @@ def main():
             gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=job.equal, force=grouped)
         torch.cuda.synchronize()
     runner.set_opts(opts_timed)                             # every dominant-kernel launch of the timed steps carries its own event pair ...
+    cal_at = lanes[0].eng.calibrated_at
+    setup_gap_ms = round(1e3 * (time.perf_counter() - cal_at), 2) if cal_at else None     # host time from the calibration's last launch to here
     if a.warmup:
         runner.run(a.warmup)                                # ... and so do the warm-up steps: they are the timed steps' twins
-        if timing:
-            torch.cuda.synchronize()
-            timing.collect()                                # rewind the event pool: the durations reported are the timed region's
+    if os.environ.get("OFMK_BENCH_EXPERIMENT_PAUSE_MS"):    # experiment only: a host-side pause between warm-up and timed region
+        torch.cuda.synchronize()
+        t_p = time.perf_counter()
+        while (time.perf_counter() - t_p) * 1e3 < float(os.environ["OFMK_BENCH_EXPERIMENT_PAUSE_MS"]):
+            pass
     elapsed, votes, last_size = runner.timed(a.steps)
     shipped_order = lanes[0].eng.tile_order                  # what the timed region ran with (later side measurements may calibrate)
     shipped_info = lanes[0].eng.tile_order_info
@@ -760,10 +782,11 @@ def main():
     kern, series = None, []
     if not a.no_kernel_events:
         kern = {}
-        if timing:
-            series = [m for m, k_ in timing.durations() if k_ == DOMINANT]
-            kern = timing.collect()            # the dominant kernel's per-launch durations from the timed region itself
+        if timing:          # the dominant kernel's per-launch durations from the timed region itself (the warm-up's launches dropped)
+            series = [m for m, k_ in timing.durations(n_chunks * (timed_steps + a.warmup) + 16) if k_ == DOMINANT][warm_launches:]
+            timing.collect()
             timing.close()
+            kern = {DOMINANT: dict(ms_total=float(np.sum(series)), launches=len(series))}
         # every kernel kind, from a short pass of its own straight after (plain launches, a pair on every one)
         kb = max(3, min(a.steps, 20))
         t_all = _hip.Timing(8 * n_chunks * kb + 16)
@@ -1124,6 +1147,7 @@ def main():
                        "self_launched": bool(os.environ.get("OFMK_BENCH_SELF_LAUNCHED"))},
         "rccl_ranks": ranks_seen if (grouped and a.backend == "nccl") else None,
         "host_ms_per_step": host_ms,            # rank 0's CPU time issuing a step / voting on one; must stay < ms_per_step
+        "setup_ms_between_calibration_and_warmup": setup_gap_ms,
         "cpu_baseline": None,
     }
     line.update(extra)

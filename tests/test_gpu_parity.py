@@ -456,15 +456,21 @@ def test_tile_orders_are_bit_identical_and_the_xcc_probe_reads_the_deal(eng):
     deal = E.probe_xcc_deal()
     assert 1 <= deal["xcds"] <= 16 and len(deal["ids_by_residue"]) == deal["xcds"] and 0.0 < deal["round_robin_fraction"] <= 1.0
     print("xcc deal:", deal)
-    # calibration on a batch big enough to time: picks an order from its own measurement, process-wide for the device
+    # calibration on a batch big enough to time: picks an order from its own measurement, kept per device AND launch shape
     big = synthetic_frames(48, 1080, 1920, seed=78)
-    info = type(eng)().calibrate_tile_order(big, force=True)
-    assert info["order"] in ("xcd", "linear") and info["xcd_ms"] > 0 and info["linear_ms"] > 0
+    wm_big = orc.shuffle_generate(P8, (32400,), 0)[None]
+    info = type(eng)().calibrate_tile_order(big, force=True, min_ms=60.0)
+    assert info["order"] in ("xcd", "linear") and info["xcd_ms"] > 0 and info["linear_ms"] > 0 and info["frames_per_launch"] == 48
     assert (info["order"] == "linear") == (info["linear_ms"] < info["xcd_ms"] or not info["round_robin"])
-    assert type(eng)().tile_order == info["order"] and type(eng)(tile_order="linear").tile_order == "linear"
-    a = type(eng)(tile_order="xcd").embed_detect(big, orc.shuffle_generate(P8, (32400,), 0)[None], L=8)
-    b = type(eng)(tile_order="linear").embed_detect(big, orc.shuffle_generate(P8, (32400,), 0)[None], L=8)
+    auto = type(eng)()
+    a = auto.embed_detect(big, wm_big, L=8)                           # same shape: uses the calibrated order, does not calibrate again
+    assert auto.tile_order == info["order"] and auto.tile_order_info["xcd_ms"] == info["xcd_ms"]
+    fixed = type(eng)(tile_order="linear" if info["order"] == "xcd" else "xcd")
+    b = fixed.embed_detect(big, wm_big, L=8)
+    assert fixed.tile_order != auto.tile_order
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    small = auto.embed_detect(big[:8], wm_big, L=8)                   # another shape, too small to calibrate: the default order
+    assert auto.tile_order == "xcd" and torch.equal(small[0], a[0][:8])
     print("tile order calibration:", info)
 
 

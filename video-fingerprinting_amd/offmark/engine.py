@@ -38,9 +38,11 @@ def balanced_chunk(n: int, cap: int) -> int:
 # Which order is faster differs from box to box by a few per cent (the builder's boxes: XCD-aware -1.4 .. -2.6 %; the driver's:
 # +5 % between BENCH_r02 and BENCH_r03), so it is MEASURED once per device and process: the first batch of at least
 # _CALIBRATE_MIN_BYTES of frames an engine marks is first run a few times in both orders, interleaved, on the caller's own
-# buffers, and the faster one is kept for every engine on that device (results are identical bit for bit either way).
+# buffers, and the faster one is kept for every engine on that device AND that launch shape (results are identical bit for bit
+# either way).  Per shape because the answer depends on it: at 300 x 1080p per launch the XCD-aware order wins by 1.5-3.4 %, at 48
+# frames per launch the linear one by 3-4 %, at 192 they tie (profiles/r4_mark_fused_pass.txt).
 # OFFMARK_TILE_ORDER = auto (default) | xcd | linear overrides; DctEngine(tile_order=...) overrides that.
-_TILE_ORDER = {}              # device index -> dict(order=..., xcd_ms=..., linear_ms=..., ...)
+_TILE_ORDER = {}              # (device index, H, W, frames per launch) -> dict(order=..., xcd_ms=..., linear_ms=..., ...)
 _XCC_DEAL = {}                # device index -> probe_xcc_deal() result
 _CALIBRATE_MIN_BYTES = 192 << 20
 
@@ -89,6 +91,8 @@ class DctEngine:
             raise ValueError(f"tile_order must be 'auto', 'xcd' or 'linear', not {order!r}")
         self._order_mode = order
         self._opts_cache = None
+        self._last_key = None
+        self.calibrated_at = None
         # range-check device-resident row maps too (costs a host synchronisation per call, so off by default; the kernels
         # clamp every entry into [0, n_wm) either way -- include/offmark_hip.h)
         self.debug_checks = os.environ.get("OFFMARK_DEBUG_CHECKS", "0") not in ("", "0")
@@ -116,27 +120,36 @@ class DctEngine:
     def device_key(self):
         return self.device.index if self.device.index is not None else self.torch.cuda.current_device()
 
+    def _order_key(self, shape):
+        return (self.device_key,) + tuple(int(x) for x in shape)
+
     @property
     def tile_order(self) -> str:
-        """The order in use: this engine's fixed choice, else the device's calibrated one, else "xcd" (not yet calibrated)."""
+        """The order in use: this engine's fixed choice, else what the last marking call's launch shape was calibrated to,
+        else "xcd" (not yet calibrated)."""
         if self._order_mode != "auto":
             return self._order_mode
-        return _TILE_ORDER.get(self.device_key, {}).get("order", "xcd")
+        return _TILE_ORDER.get(self._last_key, {}).get("order", "xcd")
 
     @property
     def tile_order_info(self) -> dict:
-        return dict(_TILE_ORDER.get(self.device_key, {}), mode=self._order_mode, in_use=self.tile_order)
+        return dict(_TILE_ORDER.get(self._last_key, {}), mode=self._order_mode, in_use=self.tile_order)
 
-    def _o(self):
-        """ctypes argument for this call's ofmk_opts: the engine's opts (flags, timing) plus the tile order."""
+    def _o(self, shape=None):
+        """ctypes argument for this call's ofmk_opts: the engine's opts (flags, timing) plus, for a call that runs the frame-writing
+        DCT kernel (``shape`` = (H, W, frames per launch)), the tile order calibrated for that shape."""
         base = self.opts
         flags = base.flags if base is not None else 0
         xcds = base.xcds if base is not None else 0
-        if not xcds:                                          # a device whose probe counted other than 8 XCDs (partition modes)
-            xcds = _TILE_ORDER.get(self.device_key, {}).get("xcds", 0)
-            xcds = 0 if xcds == 8 else xcds
-        if self.tile_order == "linear":
-            flags |= _hip.F_LINEAR_TILES
+        if shape is not None:
+            self._last_key = self._order_key(shape)
+            info = _TILE_ORDER.get(self._last_key, {})
+            if not xcds:                                      # a device whose probe counted other than 8 XCDs (partition modes)
+                xcds = info.get("xcds", 0)
+                xcds = 0 if xcds == 8 else xcds
+            order = self._order_mode if self._order_mode != "auto" else info.get("order", "xcd")
+            if order == "linear":
+                flags |= _hip.F_LINEAR_TILES
         if base is not None and flags == base.flags and xcds == base.xcds:
             return _hip.opts_ref(base)
         if flags == 0 and xcds == 0 and base is None:
@@ -145,52 +158,39 @@ class DctEngine:
         self._opts_cache = o                                  # alive until the next call
         return _hip.opts_ref(o)
 
-    def calibrate_tile_order(self, frames, out=None, min_ms: float = 250.0, max_ms: float = 800.0, force: bool = False) -> dict:
-        """Time the fused mark+verify kernel on ``frames`` (CUDA uint8 [n, H, W, 3]) in both tile orders and keep the faster
-        one for every engine on this device.  Launches go out in blocks of 4 interleaved pairs (A B B A A B B A, each mark
-        launch behind an analyze launch, as in a step; durations are the dispatches' own timestamps, one event pool per
-        order) and the device is kept busy from the first block to the last.  A device coming out of idle keeps speeding up
-        for the first few hundred milliseconds of load (DVFS: the same kernel took 0.775 ms in the first block, 0.688 ms 60 ms
-        later and 0.675 ms a second later, gpurun_out/r4a_bench_line_steps20_warmup5.json), and a choice made on that ramp
-        does not describe the state the work then runs in -- so blocks are added until at least ``min_ms`` of sustained load
-        have passed AND a block's mean duration is within 0.5 % of the previous block's (or ``max_ms`` have passed), and
-        the decision is taken on the last four blocks only.  Synchronises; ``out`` (a buffer the marked frames may be written
-        to; default: a temporary one) must not alias ``frames``.  Never run under stream capture."""
+    def _calibrate(self, key, launch, base_flags, min_ms, max_ms, chunks=1) -> dict:
+        """Core of the calibration: ``launch(opts)`` enqueues THE CALL BEING CALIBRATED (the caller's own embed / embed+detect
+        call on its own buffers) with the given ofmk_opts; it is issued in blocks of 8 (A B B A A B B A), the mark kernel's
+        launches timed by the dispatches' own timestamps (one event pool per order), the device kept busy from the first block
+        to the last.  Why the caller's whole call and not just the kernel in question: on this device every change of load
+        pattern is followed by ~10-20 ms of slower launches (power management: 3-10 ms after bench.py went from a
+        calibration made of analyze + mark launches only to its real steps, the same kernel ran 5-10 % slower,
+        profiles/r4_idle_gap.txt), so the calibration must BE the steady state it hands over to.  And a device coming out of
+        idle keeps speeding up for ~100 ms of load (first block 0.78 ms, settled 0.69 ms), so blocks are added until at least
+        ``min_ms`` of sustained load have passed and a block's mean is within 0.5 % of the previous one's (or ``max_ms`` have
+        passed); the decision is taken on the last four blocks only."""
+        import time
         t = self.torch
-        key = self.device_key
-        if key in _TILE_ORDER and not force:
-            return _TILE_ORDER[key]
-        n, H, W = self._check_frames(frames, t.uint8)
-        m = self._chunk(n, H, W)
-        src = frames[:m]
-        if out is None or out.data_ptr() == frames.data_ptr():
-            dst = t.empty_like(src)
-        else:
-            dst = self._out(out, frames)[:m]
         deal = probe_xcc_deal(self.device)
         xcds = deal["xcds"] if deal["round_robin"] else 0
-        ws = self.workspace(H, W, m)
-        wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
-        wm[0, ::2] = 1
-        stream = _hip.current_stream()
-        kinds = (1 << _hip.TIMING_KINDS.index("mark_fused"))
-        pools = {"xcd": _hip.Timing(8, kinds), "linear": _hip.Timing(8, kinds)}
-        opts = {"xcd": _hip.Opts(0, xcds, pools["xcd"].handle), "linear": _hip.Opts(_hip.F_LINEAR_TILES, xcds, pools["linear"].handle)}
-        blocks = []                                           # per block: {order: mean launch ms}
-        import time
+        kinds = (1 << _hip.TIMING_KINDS.index("mark_fused")) | (1 << _hip.TIMING_KINDS.index("mark"))
+        per_block = 4 * max(1, int(chunks)) + 4               # timed launches per order and block: 4 calls x chunks per call
+        pools = {"xcd": _hip.Timing(per_block, kinds), "linear": _hip.Timing(per_block, kinds)}
+        opts = {"xcd": _hip.Opts(base_flags & ~_hip.F_LINEAR_TILES, xcds, pools["xcd"].handle),
+                "linear": _hip.Opts(base_flags | _hip.F_LINEAR_TILES, xcds, pools["linear"].handle)}
+        blocks, settled = [], False                           # per block: {order: mean launch ms}
         t_start = time.perf_counter()
         try:
-            def launch(order):
-                _hip.check(self.lib.ofmk_stage_analyze_rgb8(src.data_ptr(), m, H, W, ws.data_ptr(), ws.numel(), stream, None))
-                _hip.check(self.lib.ofmk_stage_mark_rgb8(src.data_ptr(), dst.data_ptr(), m, H, W, wm.data_ptr(), 20.0, 1,
-                                                         ws.data_ptr(), ws.numel(), stream, _hip.opts_ref(opts[order])))
-            settled = False
             while True:
                 for order in ("xcd", "linear", "linear", "xcd", "xcd", "linear", "linear", "xcd"):
-                    launch(order)
+                    launch(_hip.opts_ref(opts[order]))
                 t.cuda.current_stream().synchronize()
-                got = {k: p.collect()["mark_fused"] for k, p in pools.items()}
-                blocks.append({k: v["ms_total"] / max(v["launches"], 1) for k, v in got.items()})
+                got = {}
+                for k, p in pools.items():
+                    c = p.collect()
+                    ms = c["mark_fused"]["ms_total"] + c["mark"]["ms_total"]
+                    got[k] = ms / max(c["mark_fused"]["launches"] + c["mark"]["launches"], 1)
+                blocks.append(got)
                 spent = 1e3 * (time.perf_counter() - t_start)
                 if len(blocks) >= 4 and spent >= min_ms:
                     now, before = sum(blocks[-1].values()), sum(blocks[-2].values())
@@ -200,22 +200,52 @@ class DctEngine:
         finally:
             for p in pools.values():
                 p.close()
-        last = blocks[-4:]
-        med = {k: float(np.mean([b[k] for b in last])) for k in ("xcd", "linear")}
-        took_ms = 1e3 * (time.perf_counter() - t_start)
+        med = {k: float(np.mean([b[k] for b in blocks[-4:]])) for k in ("xcd", "linear")}
         order = "linear" if (med["linear"] < med["xcd"] or not deal["round_robin"]) else "xcd"
-        info = dict(order=order, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5), blocks=len(blocks), launches_each=4 * len(blocks),
+        info = dict(order=order, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5), blocks=len(blocks), calls_each=4 * len(blocks),
                     first_block_ms=round(0.5 * sum(blocks[0].values()), 5), last_block_ms=round(0.5 * sum(blocks[-1].values()), 5),
-                    settled=bool(settled), calibration_ms=round(took_ms, 1), frames=int(m), height=H, width=W, xcds=deal["xcds"], round_robin=deal["round_robin"])
+                    settled=bool(settled), calibration_ms=round(1e3 * (time.perf_counter() - t_start), 1),
+                    height=key[1], width=key[2], frames_per_launch=key[3], kernel="mark+verify" if key[4] else "mark",
+                    xcds=deal["xcds"], round_robin=deal["round_robin"])
+        self.calibrated_at = time.perf_counter()              # (bench.py reports the host time between this and its first warm-up launch)
         _TILE_ORDER[key] = info
         return info
 
-    def _maybe_calibrate(self, frames, out):
-        if self._order_mode != "auto" or self.device_key in _TILE_ORDER:
-            return
-        if frames.numel() < _CALIBRATE_MIN_BYTES or self.torch.cuda.is_current_stream_capturing():
-            return
-        self.calibrate_tile_order(frames, out)
+    def _launch_marking(self, launch, frames, out, shape):
+        """Issue a marking call: ``launch(opts)`` enqueues it.  In "auto" mode the first large call of a (device, launch shape,
+        kernel) is preceded by the calibration, which runs that very call (same buffers, same arguments: the results it leaves
+        are the call's own results)."""
+        self._last_key = self._order_key(shape)
+        if (self._order_mode == "auto" and self._last_key not in _TILE_ORDER and frames.numel() >= _CALIBRATE_MIN_BYTES
+                and out.data_ptr() != frames.data_ptr() and not self.torch.cuda.is_current_stream_capturing()):
+            n = frames.shape[0]
+            self._calibrate(self._last_key, launch, self.opts.flags if self.opts is not None else 0, 250.0, 800.0,
+                            chunks=-(-n // max(int(shape[2]), 1)))
+        launch(self._o(shape))
+
+    def calibrate_tile_order(self, frames, out=None, min_ms: float = 250.0, max_ms: float = 800.0, force: bool = False) -> dict:
+        """Explicit calibration of the fused mark+verify call on ``frames`` (CUDA uint8 [n, H, W, 3]) with a test watermark,
+        for callers that want it done at a moment of their choosing (see _calibrate).  Synchronises; ``out`` (default: a
+        temporary buffer) must not alias ``frames``.  Returns the calibration record of this device and launch shape."""
+        t = self.torch
+        n, H, W = self._check_frames(frames, t.uint8)
+        cf = self._chunk(n, H, W)
+        fused = not (self.opts is not None and self.opts.flags & _hip.F_SEPARATE_DETECT)
+        key = self._order_key((H, W, cf, int(fused)))
+        self._last_key = key
+        if key in _TILE_ORDER and not force:
+            return _TILE_ORDER[key]
+        dst = t.empty_like(frames) if out is None or out.data_ptr() == frames.data_ptr() else self._out(out, frames)
+        wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
+        wm[0, ::2] = 1
+        counts = t.empty((n, 8), dtype=t.int32, device=self.device)
+        ws = self.workspace(H, W, cf)
+        stream = _hip.current_stream()
+
+        def launch(o):
+            _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), dst.data_ptr(), n, H, W, wm.data_ptr(), 1, None, 20.0, 8,
+                                                       counts.data_ptr(), None, cf, ws.data_ptr(), ws.numel(), stream, o))
+        return self._calibrate(key, launch, self.opts.flags if self.opts is not None else 0, min_ms, max_ms, chunks=-(-n // cf))
 
     def _check_frames(self, frames, dtype):
         t = self.torch
@@ -282,12 +312,14 @@ class DctEngine:
         wm = self._wm(wm, N)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
-        self._maybe_calibrate(frames, out)
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
-        _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
-                                            _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(),
-                                            _hip.current_stream(), self._o()))
+        stream = _hip.current_stream()
+
+        def launch(o):
+            _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
+                                                _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(), stream, o))
+        self._launch_marking(launch, frames, out, (H, W, cf, 0))
         return out
 
     def detect(self, frames, L, alpha=20, want_bits=False):
@@ -325,13 +357,16 @@ class DctEngine:
         out = self._out(out, frames)
         counts = t.empty((n, L), dtype=t.int32, device=self.device)
         bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
-        self._maybe_calibrate(frames, out)
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
-        _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
-                                                   wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
-                                                   counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(),
-                                                   _hip.current_stream(), self._o()))
+        stream = _hip.current_stream()
+        fused = not (self.opts is not None and self.opts.flags & _hip.F_SEPARATE_DETECT)
+
+        def launch(o):
+            _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
+                                                       wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
+                                                       counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), stream, o))
+        self._launch_marking(launch, frames, out, (H, W, cf, int(fused)))
         return out, counts, bits
 
     def payloads(self, counts, n_bits: int, perm, out=None):
