@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--group", type=int, default=0, help="steps issued per host iteration (0 = auto: 1 for shards of >= 100 "
                                                          "1080p frames, else as many as make ~300 frames)")
     ap.add_argument("--no-graph", action="store_true", help="never capture the step as a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="capture the step(s) as a hipGraph whatever the shard size (experiments)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (a one-GPU box cannot run RCCL across ranks)")
@@ -354,7 +355,7 @@ def main():
     from offmark import engine as engine_mod
     from offmark import fingerprint as fp
     from offmark.degenerator.de_shuffler import DeShuffler
-    from offmark.dist.vote import gather_payloads, init_from_env, shard_range, vote_segments
+    from offmark.dist.vote import gather_payloads, group_segment_ids, init_from_env, shard_range, vote_segments
     from offmark.engine import DctEngine, balanced_chunk, default_chunk_frames
     from offmark.generator.shuffler import Shuffler
     from offmark.synthetic import synthetic_frames
@@ -619,15 +620,10 @@ def main():
 
         def ids_for(self, size):
             """segment ids of the gathered rows of a group of `size` steps, rank-major [ranks, size, n_per_rank]: step g's segment s
-            votes under id g * S + s."""
+            votes under id g * S + s (offmark.dist.vote.group_segment_ids)."""
             if size not in self._ids:
                 j = self.j
-                if size == 1:
-                    self._ids[size] = j.seg_global
-                else:
-                    ranks = j.total_frames // max(j.n, 1)
-                    seg = j.seg_global.reshape(ranks, 1, j.n)
-                    self._ids[size] = (np.arange(size)[None, :, None] * self.S_ids + seg).reshape(-1)
+                self._ids[size] = group_segment_ids(j.seg_global, j.total_frames // max(j.n, 1), size)
             return self._ids[size]
 
         def enqueue(self, g, size):
@@ -737,7 +733,7 @@ def main():
             g_ = 1
         if not j.equal:
             g_ = 1
-        return g_, bool(small and not a.no_graph and a.streams == 1)
+        return g_, bool((small or a.graph) and not a.no_graph and a.streams == 1)
 
     G, use_graph = group_policy(job)
     runner = Runner(job, n_lanes=a.streams, group=G, graph=use_graph, emulate=bool(emu))

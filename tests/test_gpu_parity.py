@@ -1228,6 +1228,7 @@ def test_bench_two_ranks_gloo_on_one_device(config, launcher):
     assert line["n_gpus"] == 2 and line["payload_bit_exact"]
     assert line["collective"] == {"backend": "gloo", "ranks": 2, "self_launched": launcher == "self"} and line["rccl_ranks"] is None
     assert line["config"]["frames_per_gpu"] == (8 if config == 2 else 4 * 8)      # config 4: 8 segments / 2 ranks x 8 frames
+    assert line["config"]["steps_per_host_iteration"] == 3 and line["config"]["hipgraph"]   # small shards: the three steps are ONE graph, gathered and voted on together
     if config == 2:
         assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"] and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["dwtdctsvd"]["payload_ok"]

@@ -32,6 +32,9 @@ for step in "$@"; do
     emu4)      run 300 emulate8_config4 $B --config 4 --emulate-world 8 ;;
     emu5)      run 300 emulate8_config5 $B --config 5 --emulate-world 8 ;;
     emu5svd)   run 300 emulate8_config5_dwtdctsvd $B --config 5 --emulate-world 8 --codec dwtdctsvd ;;
+    emu4w2)    run 300 emulate2_config4 $B --config 4 --emulate-world 2 ;;
+    emu4w4)    run 300 emulate4_config4 $B --config 4 --emulate-world 4 ;;
+    sustained) run 300 bench_sustained_20000_steps $B --steps 20000 --warmup 5 --no-extras ;;
     prof)      run 900 prof bash tools/prof.sh ${TAG} ;;
     profsvd)   run 900 profsvd bash tools/prof.sh ${TAG}svd --codec dwtdctsvd ;;
     profsvd8)  run 900 profsvd8 bash tools/prof.sh ${TAG}svd8 --codec dwtdctsvd --blk 8 ;;
@@ -39,7 +42,7 @@ for step in "$@"; do
     *) echo "unknown step $step" ;;
   esac
 done
-for f in $O/${TAG}_bench_*.out $O/${TAG}_emulate8_*.out; do [ -s "$f" ] && mv "$f" "${f%.out}.json"; done
+for f in $O/${TAG}_bench_*.out $O/${TAG}_emulate*.out; do [ -s "$f" ] && mv "$f" "${f%.out}.json"; done
 python - <<PY
 import glob, json
 for f in sorted(glob.glob("$O/${TAG}_*.json")):

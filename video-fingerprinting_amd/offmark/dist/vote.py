@@ -148,6 +148,36 @@ def vote_segments(patterns, segment_ids):
             for w, size in zip(winners, sizes)}
 
 
+def group_segment_ids(segment_ids, ranks: int, steps: int):
+    """Segment ids for the rows of a GROUP of ``steps`` steps gathered in one collective.
+
+    Small shards are issued several steps per host iteration (a 48-frame segment is 0.2 ms of GPU work): every rank
+    contributes its ``steps * n`` payload rows in (step, frame) order, so the all-gather returns them rank-major,
+    [ranks, steps, n].  ``segment_ids`` are the ids of ONE step's rows in rank-major order ([ranks * n]); the result gives
+    step g's segment s the id ``g * S + s`` (S = max id + 1), so that ONE vote_segments call resolves every step of the
+    group and votes never mix steps."""
+    seg = np.asarray(segment_ids)
+    if steps == 1:
+        return seg
+    n = seg.size // max(ranks, 1)
+    S = int(seg.max()) + 1 if seg.size else 1
+    return (np.arange(steps)[None, :, None] * S + seg.reshape(ranks, 1, n)).reshape(-1)
+
+
+def vote_groups(patterns, segment_ids, ranks: int, steps: int):
+    """Per-step, per-segment votes of a gathered group: a list (one entry per step) of {segment: (pattern, frequency)}.
+    ``patterns``: [ranks * steps * n, L] rank-major rows; ``segment_ids``: one step's ids ([ranks * n])."""
+    seg = np.asarray(segment_ids)
+    S = int(seg.max()) + 1 if seg.size else 1
+    votes = vote_segments(patterns, group_segment_ids(seg, ranks, steps))
+    if steps == 1:
+        return [votes]
+    out = [dict() for _ in range(steps)]
+    for key, v in votes.items():
+        out[key // S][key % S] = v
+    return out
+
+
 def soft_vote(soft_sums, perm, segment_ids=None):
     """Build extension (not reference semantics): combine per-frame soft sums [n, L] (offmark's
     DctEngine.detect_soft) by ADDING them over the frames of each segment, undo the key permutation and read
