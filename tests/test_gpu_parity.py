@@ -661,6 +661,10 @@ def test_c_abi_calls_are_graph_capturable(eng):
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref_out) and torch.equal(counts, ref_counts) and torch.equal(pay, ref_pay)
+    del graph, counts, pay
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("codec", ["dct", "dct-detect", "svd4", "svd8", "planar"])
@@ -728,6 +732,10 @@ def test_several_steps_in_one_graph_replay_like_eager(eng, codec):
         if codec != "dct-detect":
             assert all(torch.equal(a, b) for a, b in zip(outs, ref[0])), (codec, rep)
     assert (pays[0].cpu().numpy() == np.where((np.arange(n) % 2)[:, None] == 0, P8, 1 - P8)).all()
+    del graph                                      # release the graph and its private pool here, not at some later collection
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("codec", ["dct", "dwtdctsvd"])
