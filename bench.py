@@ -355,7 +355,8 @@ def main():
     from offmark import engine as engine_mod
     from offmark import fingerprint as fp
     from offmark.degenerator.de_shuffler import DeShuffler
-    from offmark.dist.vote import gather_payloads, group_segment_ids, init_from_env, shard_range, vote_segments
+    from offmark.dist.steps import StepPipeline
+    from offmark.dist.vote import gather_payloads, init_from_env, shard_range, vote_segments
     from offmark.engine import DctEngine, balanced_chunk, default_chunk_frames
     from offmark.generator.shuffler import Shuffler
     from offmark.synthetic import synthetic_frames
@@ -486,48 +487,24 @@ def main():
     opts_plain = _hip.Opts(flags, 0, None)
 
     # ---- the step over one job ---------------------------------------------------------------------------------
-    class Runner:
-        """Issues steps of one job: lanes (engine + output buffer + stream), the side stream with the all-gather and the
-        download, the host-side vote; G steps per host iteration, optionally as one captured hipGraph."""
+    class Runner(StepPipeline):
+        """offmark.dist.steps.StepPipeline (lanes, grouped hipGraph replay on two branches, side-stream gather + download, host vote)
+        over one job of this benchmark: what a step is, the emulated gather, the contract's fences and the checks."""
 
         def __init__(self, j, n_lanes=1, group=1, graph=False, emulate=False):
-            self.j, self.G, self.use_graph, self.emulate = j, max(1, group), graph, emulate
+            self.j, self.emulate = j, emulate
             self.chunk = a.chunk or default_chunk_frames(H, W)
             self.cf = balanced_chunk(max(j.n, 1), self.chunk)
             self.n_chunks = max(1, -(-j.n // self.cf))
-            self.lanes = []
-            for i in range(n_lanes):
-                self.add_lane(torch.cuda.current_stream() if i == 0 else torch.cuda.Stream())
-            self.side = torch.cuda.Stream()            # all-gather + download: off the compute stream, so a slow peer never
-            self.handoff = [torch.cuda.Event() for _ in range(2)]      # stalls this rank's next step
-            self.ready = [torch.cuda.Event() for _ in range(2)]
-            rows = j.total_frames * self.G
-            self.host = [torch.empty((rows, L), dtype=torch.uint8).pin_memory() for _ in range(2)]
-            self.host_s = {"enqueue": 0.0, "vote": 0.0}        # host-side seconds spent issuing work / voting (not waiting)
-            self.S_ids = int(j.seg_global.max()) + 1 if j.total_frames else 1
-            self._ids = {}
+            src = j.planes if planar else j.frames
+            super().__init__(dev, j.n, L, j.seg_global,
+                             make_engine=lambda: DctEngine(device=dev, chunk_frames=self.chunk, opts=opts_plain, tile_order=a.tile_order),
+                             make_out=lambda: torch.empty_like(src) if j.mode == "embed_detect" else None,
+                             issue=self.issue_step, lanes=n_lanes, group=group, graph=graph, gather=self.gather_rows)
             if emulate:        # the gathered buffer of an M-rank job, rank-major [M, G, n, L]: the other ranks' parts are pre-filled
                 ew = j.shard_world
                 per_rank = torch.from_numpy(j.expected_rows).to(dev).view(ew, 1, j.n, L).expand(ew, self.G, j.n, L).contiguous()
                 self.everyone = [per_rank.clone() for _ in range(2)]
-
-        def add_lane(self, stream):
-            j = self.j
-            src = j.planes if planar else j.frames
-            mk_eng = lambda: DctEngine(device=dev, chunk_frames=self.chunk, opts=opts_plain, tile_order=a.tile_order)  # noqa: E731
-            mk_out = lambda: torch.empty_like(src) if j.mode == "embed_detect" else None  # noqa: E731
-            # a graphed group runs its steps on TWO branches (own engine = own workspace, own output buffer): consecutive steps
-            # of a small shard overlap, one step's tail and launch gaps under the other's kernels
-            two = self.use_graph and self.G >= 2 and j.n > 0
-            lane = SimpleNamespace(eng=mk_eng(), out=mk_out(), eng2=mk_eng() if two else None, out2=mk_out() if two else None, stream=stream,
-                                   pay=torch.empty((2, self.G, max(j.n, 0), L), dtype=torch.uint8, device=dev), graph=[None, None])
-            # pay[parity]: a group's payloads stay untouched while the side stream gathers and downloads them and the lane already
-            # runs its next group into the other half (one captured graph per half: a graph's addresses are fixed)
-            self.lanes.append(lane)
-            return lane
-
-        def engines(self):
-            return [e for lane in self.lanes for e in (lane.eng, lane.eng2) if e is not None]
 
         def set_opts(self, o):
             for e in self.engines():
@@ -538,16 +515,9 @@ def main():
                 e._order_mode = order
             self.drop_graphs()
 
-        def drop_graphs(self):
-            for lane in self.lanes:
-                lane.graph = [None, None]
-
-        def hot_path(self, lane, slot=0, par=0, branch=0):
-            """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames -> lane.pay[par, slot]."""
+        def issue_step(self, e, out, slot):
+            """embed + detect (config 5: detect only) + per-frame payloads for this rank's frames -> slot [n, L] uint8 on the device."""
             j = self.j
-            e, out = (lane.eng, lane.out) if branch == 0 else (lane.eng2, lane.out2)
-            if j.n == 0:
-                return
             if j.mode == "detect":
                 if a.codec == "dct":
                     counts, _ = e.detect(j.frames, L, alpha=a.alpha)
@@ -559,130 +529,28 @@ def main():
                 _, counts, _ = e.embed_detect(j.frames, j.wm_dev, L=L, alpha=a.alpha, wm_row=j.rows_dev, out=out)
             else:
                 _, counts, _ = e.svd_embed_detect(j.frames, j.wm_dev, L=L, scale=15, wm_row=j.rows_dev, out=out, blk=a.blk)
-            e.payloads(counts, n_bits, perm_dev, out=lane.pay[par, slot])    # [n, L] uint8, on device
+            e.payloads(counts, n_bits, perm_dev, out=slot)
+
+        def hot_path(self, lane):
+            self.step(lane)
+
+        def gather_rows(self, mine, g, size):
+            if self.emulate:                                               # a device copy where the RCCL all-gather would be
+                buf = self.everyone[g & 1]
+                buf[0, :size].copy_(mine.view(size, self.j.n, L))
+                return buf[:, :size].reshape(-1, L)
+            if a.backend == "gloo" and grouped:                            # rehearsal: gloo gathers host tensors
+                return gather_payloads(mine.cpu(), equal_shards=self.j.equal, force=grouped)
+            return gather_payloads(mine, equal_shards=self.j.equal, force=grouped)        # RCCL all-gather (N > 1)
 
         def prepare(self):
             """One-time set-up, not a workload step: allocate the scratch for the chunk size in use, let the runtime load the code
-            objects and the engine calibrate its tile order (one full-size pass, so that profiles only ever see full-size launches);
-            capture the G-step graph when asked.  Even --warmup 0 then times steady-state steps."""
-            j = self.j
-            # first use of the download path (side stream, page-locked landing buffers, events) BEFORE the device is brought to its
-            # operating state: in a kernel trace the first non-blocking D2H copy of the process held the host for milliseconds
-            # (6 ms under rocprofv3) right after the first step, and every idle gap of that size is followed by ~15 ms of slower
-            # launches (profiles/r4_idle_gap.txt) -- exactly where a short timed region sits
-            with torch.cuda.stream(self.side):
-                scratch = torch.zeros((1, L), dtype=torch.uint8, device=dev)
-                for h, ev in zip(self.host, self.ready):
-                    if h.shape[0]:
-                        h[:1].copy_(scratch, non_blocking=True)
-                    ev.record()
-                for ev in self.handoff:
-                    ev.record()
-            torch.cuda.synchronize()
-            for lane in self.lanes:
-                for b, e in enumerate((lane.eng, lane.eng2)):
-                    if e is None:
-                        continue
-                    if j.n:
-                        e.workspace(H, W, e._chunk(j.n, H, W))
-                    with torch.cuda.stream(lane.stream):
-                        self.hot_path(lane, branch=b)
-            torch.cuda.synchronize()
-            if self.use_graph and j.n:
-                for lane in self.lanes:
-                    for par in (0, 1):
-                        self.capture(lane, par)
-
-        def capture(self, lane, par):
-            """G steps of this lane as ONE hipGraph (C-ABI calls only enqueue work, so they capture)."""
-            cs, fork = torch.cuda.Stream(), torch.cuda.Stream()
-            two = lane.eng2 is not None
-
-            def body():
-                if two:
-                    fork.wait_stream(cs)                            # fork: odd steps on a second branch of the graph
-                for g_ in range(self.G):
-                    if two and g_ % 2:
-                        with torch.cuda.stream(fork):
-                            self.hot_path(lane, g_, par, branch=1)
-                    else:
-                        self.hot_path(lane, g_, par)
-                if two:
-                    cs.wait_stream(fork)                            # join
-            with torch.cuda.stream(cs):
-                body()
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=cs):
-                    body()
-            torch.cuda.synchronize()
-            lane.graph[par] = graph
-
-        def ids_for(self, size):
-            """segment ids of the gathered rows of a group of `size` steps, rank-major [ranks, size, n_per_rank]: step g's segment s
-            votes under id g * S + s (offmark.dist.vote.group_segment_ids)."""
-            if size not in self._ids:
-                j = self.j
-                self._ids[size] = group_segment_ids(j.seg_global, j.total_frames // max(j.n, 1), size)
-            return self._ids[size]
-
-        def enqueue(self, g, size):
-            """GPU half of group g (`size` steps); then, on a side stream, the all-gather of the payloads and their download into
-            pinned memory."""
-            t_in = time.perf_counter()
-            j = self.j
-            lane = self.lanes[g % len(self.lanes)]
-            par = (g // len(self.lanes)) & 1
-            timed_launches = lane.eng.opts is not None and lane.eng.opts.timing
-            with torch.cuda.stream(lane.stream):
-                if self.use_graph and size == self.G and not timed_launches and j.n:
-                    if lane.graph[par] is None:
-                        self.capture(lane, par)
-                    lane.graph[par].replay()
-                else:
-                    for g_ in range(size):
-                        self.hot_path(lane, g_, par)
-                self.handoff[g & 1].record()
-            self.last = (lane, par)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.handoff[g & 1])
-                mine = lane.pay[par, :size].reshape(size * j.n, L)
-                if self.emulate:                                               # a device copy where the RCCL all-gather would be
-                    buf = self.everyone[g & 1]
-                    buf[0, :size].copy_(lane.pay[par, :size])
-                    everyone = buf[:, :size].reshape(-1, L)
-                elif a.backend == "gloo" and grouped:                          # rehearsal: gloo gathers host tensors
-                    everyone = gather_payloads(mine.cpu(), equal_shards=j.equal, force=grouped)
-                else:
-                    everyone = gather_payloads(mine, equal_shards=j.equal, force=grouped)      # RCCL all-gather (N > 1)
-                self.host[g & 1][:everyone.shape[0]].copy_(everyone, non_blocking=True)
-                self.ready[g & 1].record()
-            self.host_s["enqueue"] += time.perf_counter() - t_in
-            return everyone.shape[0]
-
-        def finish(self, g, size, rows):
-            """Host half of group g: the reference's cross-frame Counter vote, once its payloads have landed.
-            It runs while the GPU is already working on group g+1 (double-buffered)."""
-            self.ready[g & 1].synchronize()
-            t_in = time.perf_counter()
-            v = vote_segments(self.host[g & 1][:rows].numpy(), self.ids_for(size))
-            self.host_s["vote"] += time.perf_counter() - t_in
-            return v
-
-        def plan(self, steps):
-            full, rest = divmod(steps, self.G)
-            return [self.G] * full + ([rest] if rest else [])
-
-        def run(self, steps):
-            """`steps` steps in groups; returns (the last group's votes, that group's size)."""
-            sizes = self.plan(steps)
-            prev = None
-            for g, size in enumerate(sizes):
-                rows = self.enqueue(g, size)
-                if prev is not None:
-                    self.finish(*prev)
-                prev = (g, size, rows)
-            return self.finish(*prev), prev[1]
+            objects and the engine calibrate its tile order (one full-size pass, so that profiles only ever see full-size launches),
+            exercise the download path, capture the G-step graphs when asked.  Even --warmup 0 then times steady-state steps."""
+            if self.j.n:
+                for e in self.engines():
+                    e.workspace(H, W, e._chunk(self.j.n, H, W))
+            super().prepare()
 
         def fence(self):
             torch.cuda.synchronize()
@@ -765,11 +633,6 @@ def main():
     setup_gap_ms = round(1e3 * (time.perf_counter() - cal_at), 2) if cal_at else None     # host time from the calibration's last launch to here
     if a.warmup:
         runner.run(a.warmup)                                # ... and so do the warm-up steps: they are the timed steps' twins
-    if os.environ.get("OFMK_BENCH_EXPERIMENT_PAUSE_MS"):    # experiment only: a host-side pause between warm-up and timed region
-        torch.cuda.synchronize()
-        t_p = time.perf_counter()
-        while (time.perf_counter() - t_p) * 1e3 < float(os.environ["OFMK_BENCH_EXPERIMENT_PAUSE_MS"]):
-            pass
     elapsed, votes, last_size = runner.timed(a.steps)
     shipped_order = lanes[0].eng.tile_order                  # what the timed region ran with (later side measurements may calibrate)
     shipped_info = lanes[0].eng.tile_order_info
@@ -797,7 +660,7 @@ def main():
 
     # correctness of what was timed: every frame's payload, every segment's vote (and the leak's copy sequence)
     want_mine = job.expected_rows[job.first:job.first + n] if n else np.zeros((0, L), np.uint8)
-    got_mine = runner.last[0].pay[runner.last[1], 0].cpu().numpy() if n else np.zeros((0, L), np.uint8)
+    got_mine = runner.last_payloads().cpu().numpy() if n else np.zeros((0, L), np.uint8)
     ber = float((got_mine != want_mine).mean()) if n else 0.0
     votes_ok = runner.votes_ok(votes, last_size)
     payload_ok = bool((got_mine == want_mine).all())
@@ -833,9 +696,6 @@ def main():
                 el_o, _, _ = runner.timed(a.steps)
                 kk = t_ab.collect()["mark_fused"]
                 res[order].append((1e3 * el_o / a.steps, kk["ms_total"] / max(kk["launches"], 1)))
-                if os.environ.get("OFMK_BENCH_DEBUG"):
-                    sys.stderr.write(f"mark_order pass {order}: {1e3 * el_o / a.steps:.4f} ms/step, kernel {kk['ms_total'] / max(kk['launches'], 1):.4f} ms x {kk['launches']}, "
-                                     f"host {({k: round(1e3 * v / a.steps, 4) for k, v in runner.host_s.items()})}\n")
             runner.set_order(a.tile_order)
             runner.set_opts(opts_plain)
             t_ab.close()
