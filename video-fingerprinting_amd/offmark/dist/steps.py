@@ -135,7 +135,9 @@ class StepPipeline:
             body()
             t.cuda.synchronize()
             graph = t.cuda.CUDAGraph()
-            with t.cuda.graph(graph, stream=cs):
+            # thread_local: only THIS thread's calls are checked against the capture -- a collective library's watchdog thread
+            # (RCCL: event queries on its own streams) must not invalidate it
+            with t.cuda.graph(graph, stream=cs, capture_error_mode="thread_local"):
                 body()
         t.cuda.synchronize()
         lane.graph[par] = graph
