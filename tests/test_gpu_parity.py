@@ -1155,7 +1155,7 @@ def test_bench_configs_run_at_one_gpu(config, extra):
 
 def test_bench_config3_4k_at_its_stated_size():
     """BASELINE.json configs[2] (4K, HBM-bound stress) AT ITS STATED SIZE: 1000 frames of 3840x2160 per step = 24.9 GB in +
-    24.9 GB out, twelve equal internal chunks under the default 2 GiB cap.  Payloads exact; the path must hold
+    24.9 GB out, three equal internal chunks (334 frames) under the default 8 GiB cap.  Payloads exact; the path must hold
     >= 0.55 of the 8 TB/s spec (measured 0.62, profiles/r3_bench_config3_4k_1000frames.json) in the timed region or in
     the pass right after it (a short timed region from idle sits on the clock ramp)."""
     import json

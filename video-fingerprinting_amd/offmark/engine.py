@@ -13,10 +13,12 @@ import numpy as np
 from . import _hip
 
 # Frames per internal chunk.  Measured on MI355X (profiles/): chunks small enough to stay in the
-# 256 MiB Infinity Cache between the analyze and apply passes do not pay -- the kernels are not
-# HBM-limited yet and short launches lose more to launch gaps and tails -- so the default is
-# large chunks (2 GiB of frames); OFFMARK_CHUNK_BYTES overrides (DESIGN.md "chunking").
-_CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 2 << 30))
+# 256 MiB Infinity Cache between the analyze and apply passes do not pay -- short launches lose more to
+# their ramps and tails than the cached second read gains (round 2, and again in round 4 with graph replay:
+# 300 frames as 15 x 20 run at 214 k frames/s against 267 k in one launch) -- so chunks are as large as
+# the cap allows: 8 GiB of frames by default (round 4; 2 GiB until then: config 4's 384 frames in one launch
+# instead of two +2.6 %, 4K in chunks of 250-334 instead of 84 +2-5 %).  OFFMARK_CHUNK_BYTES overrides.
+_CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 8 << 30))
 
 
 def default_chunk_frames(H: int, W: int, bytes_per_sample: int = 1) -> int:
