@@ -311,6 +311,24 @@ def plugin_yuv32f_rates(H, W, alpha, frame_u8):
     return out
 
 
+class stdout_to_stderr:
+    """File-descriptor-level redirection of stdout into stderr for the duration of a block: native libraries print there
+    (RCCL writes a five-line version banner to STDOUT when its first communicator comes up), and this program's stdout
+    carries exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD
     `python -m torch.distributed.run` (one process per GPU over RCCL), relay rank 0's JSON line and the exit code.
@@ -363,7 +381,8 @@ def main():
 
     if a.single_device:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world = init_from_env(a.backend, force=a.rehearse_collectives)
+    with stdout_to_stderr():
+        rank, world = init_from_env(a.backend, force=a.rehearse_collectives)
     grouped = world > 1 or a.rehearse_collectives          # a process group exists: run the collectives
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
@@ -375,9 +394,11 @@ def main():
     flags = _hip.F_SEPARATE_DETECT if a.separate_detect else 0
     ranks_seen = 1
     if grouped:                                   # how many ranks the collective library really connected: sum of ones
-        one = torch.ones(1, dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(one)
-        ranks_seen = int(one.item())
+        with stdout_to_stderr():                  # the first collective brings the communicator up (RCCL prints its banner here)
+            one = torch.ones(1, dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(one)
+            ranks_seen = int(one.item())
+            torch.cuda.synchronize()
 
     cfg = a.config
     H = a.height or (2160 if cfg == 3 else 1080)

@@ -1099,6 +1099,7 @@ def test_bench_dry_run_of_the_collective_path():
                         "--height", "240", "--width", "320", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:400]        # ONE line on stdout: RCCL's version banner goes to stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
