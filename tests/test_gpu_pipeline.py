@@ -306,6 +306,24 @@ def test_timing_options_do_not_dangle(eng):
     assert e2.opts._timing.collect()["mark"]["launches"] == 1
     import torch
     torch.cuda.synchronize()
+    # the float32-YUV DwtDctSvd entry points honour the timing object too (both block sizes), and the planar kernels
+    # report under kinds of their own
+    t3 = _hip.Timing(16)
+    e3 = DctEngine(opts=t3.opts())
+    yuv = torch.rand((1, H, W, 3), device="cuda") * 255
+    for blk in (4, 8):
+        e3.svd_encode_yuv(yuv, wm, scale=15, blk=blk)
+        e3.svd_decode_yuv(yuv, scale=15, blk=blk)
+    got = t3.collect()
+    assert got["svd"]["launches"] == 4 and got["svd"]["ms_total"] > 0
+    planes = e3.rgb_to_yuv420(f)
+    e3.embed_detect_yuv420(planes, H, W, wm, 8)
+    got = t3.collect()
+    assert got["planar_analyze"]["launches"] == 1 and got["planar_mark"]["launches"] == 1 and got["finalize"]["launches"] == 1
+    assert [k for _, k in t3.durations()] == []                       # collect() rewound the pool
+    e3.detect_yuv420(planes, H, W, 8)
+    assert [k for _, k in t3.durations()] == ["planar_analyze", "finalize"]     # launch order, kinds by name
+    t3.close()
 
 
 @pytest.mark.parametrize("pix_fmt", ["rgb24", "yuv420p"])
