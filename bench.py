@@ -37,7 +37,7 @@ payloads over the ranks (RCCL; a no-op on one GPU) and take the cross-frame vote
 Small shards (a 48-frame segment is 0.2 ms of GPU work, less than the host needs to issue a step): `--group G` (default: auto)
 issues G steps per host iteration -- the G steps' kernels are replayed as ONE captured hipGraph, their payloads are gathered
 and downloaded once, and the host votes on all G steps' payloads in one vectorised call; every step still embeds, detects,
-reduces and votes on its own batch.
+reduces and votes on its own batch (offmark.dist.steps.StepPipeline, which the Runner below specialises).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (config 2: the fused mark+verify kernel:
 it re-reads each frame, writes the marked frame and analyzes it).  Launch durations (`kernels`) come
