@@ -92,6 +92,7 @@ class DctEngine:
         if order not in ("auto", "xcd", "linear"):
             raise ValueError(f"tile_order must be 'auto', 'xcd' or 'linear', not {order!r}")
         self._order_mode = order
+        self.auto_calibrate = True        # "auto" mode only: callers whose frames cross PCIe anyway (the plugin pipeline) switch it off
         self._opts_cache = None
         self._last_key = None
         self.calibrated_at = None
@@ -218,7 +219,7 @@ class DctEngine:
         kernel) is preceded by the calibration, which runs that very call (same buffers, same arguments: the results it leaves
         are the call's own results)."""
         self._last_key = self._order_key(shape)
-        if (self._order_mode == "auto" and self._last_key not in _TILE_ORDER and frames.numel() >= _CALIBRATE_MIN_BYTES
+        if (self._order_mode == "auto" and self.auto_calibrate and self._last_key not in _TILE_ORDER and frames.numel() >= _CALIBRATE_MIN_BYTES
                 and out.data_ptr() != frames.data_ptr() and not self.torch.cuda.is_current_stream_capturing()):
             n = frames.shape[0]
             self._calibrate(self._last_key, launch, self.opts.flags if self.opts is not None else 0, 250.0, 800.0,
