@@ -219,7 +219,9 @@ class DctEngine:
         kernel) is preceded by the calibration, which runs that very call (same buffers, same arguments: the results it leaves
         are the call's own results)."""
         self._last_key = self._order_key(shape)
-        if (self._order_mode == "auto" and self.auto_calibrate and self._last_key not in _TILE_ORDER and frames.numel() >= _CALIBRATE_MIN_BYTES
+        pinned = self.opts is not None and (self.opts.flags & _hip.F_LINEAR_TILES or self.opts.xcds)     # the caller's opts fix the order already
+        if (self._order_mode == "auto" and self.auto_calibrate and not pinned and self._last_key not in _TILE_ORDER
+                and frames.numel() >= _CALIBRATE_MIN_BYTES
                 and out.data_ptr() != frames.data_ptr() and not self.torch.cuda.is_current_stream_capturing()):
             n = frames.shape[0]
             self._calibrate(self._last_key, launch, self.opts.flags if self.opts is not None else 0, 250.0, 800.0,
