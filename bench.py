@@ -44,7 +44,12 @@ it re-reads each frame, writes the marked frame and analyzes it).  Launch durati
 from HIP event pairs the library attaches to every kernel dispatch of the timed steps
 (hipExtLaunchKernelGGL start/stop events on the launch stream: the dispatch's own timestamps, no marker
 packets).  `mark_order` times the same K steps with the fused mark kernel in both tile orders, interleaved in this
-process, next to the engine's own calibration and the workgroup -> XCD deal the hardware reported.
+process, next to the policy the timed region ran under (default: the library's static rule on the launch size; no
+measurement) and the workgroup -> XCD deal the hardware reported.  `embed_only` / `detect_only`: the two operations
+tests/mark.py and tests/detect.py perform, 20 steps each after the timed region (6 and 3 B/px algorithmic).
+At N > 1 only `value` and `second_pass` are measured unless --side-measurements is given; an exception on any rank ends the
+whole job with a non-zero exit and no line (never a rank left behind in a barrier), and every rank binds itself to the cores of
+its GPU's NUMA node before anything touches the GPU (`placement`).
 `roofline.traffic` (PMC-measured HBM bytes per launch) is taken from
 profiles/ only when that profile was made from exactly the kernel sources that are running (hash stamp),
 else null.  `cpu_baseline` is the plain-C restatement of the reference algorithm (oracle/offmark_oracle.c,
@@ -95,8 +100,12 @@ def parse():
     ap.add_argument("--blk", type=int, default=4, choices=[4, 8], help="DwtDctSvd block size (--codec dwtdctsvd)")
     ap.add_argument("--pixfmt", choices=["rgb24", "i420", "nv12"], default="rgb24",
                     help="frame layout in HBM (config 2/3, DCT codec): interleaved rgb24 (the metric) or 4:2:0 planes")
-    ap.add_argument("--tile-order", choices=["auto", "xcd", "linear"], default="auto",
-                    help="tile order of the fused mark kernel: auto = the engine's per-device calibration (default)")
+    ap.add_argument("--tile-order", choices=["auto", "xcd", "linear", "calibrate"], default="auto",
+                    help="tile order of the fused mark kernel: auto = the library's static rule on the launch size (default, no "
+                         "measurement); calibrate = the engine measures once per size bucket at set-up")
+    ap.add_argument("--side-measurements", action="store_true",
+                    help="N > 1: also run the side measurements (default there: value and second_pass only)")
+    ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to its GPU's NUMA-local cores")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one GPU rehearses rank 0 of an M-rank job (see module text); needs --gpus 1")
     ap.add_argument("--group", type=int, default=0, help="steps issued per host iteration (0 = auto: 1 for shards of >= 100 "
@@ -295,9 +304,10 @@ def plugin_yuv32f_rates(H, W, alpha, frame_u8):
         marked = enc.encode(yuv0.copy())
         bits = dec.decode(marked)                             # warm: allocations, code objects
         k = 8
+        copies = [yuv0.copy() for _ in range(k)]              # the caller's frames exist before the call: not part of its time
         t0 = time.perf_counter()
-        for _ in range(k):
-            marked = enc.encode(yuv0.copy())
+        for c_ in copies:
+            marked = enc.encode(c_)
         t1 = time.perf_counter()
         for _ in range(k):
             bits = dec.decode(marked)
@@ -306,7 +316,7 @@ def plugin_yuv32f_rates(H, W, alpha, frame_u8):
                          encode_decode_fps=round(k / (t2 - t0), 1), calls=k,
                          payload_ok=bool(np.array_equal(deg.degenerate(bits), PAYLOAD)))
     out["note"] = (f"DctEncoder.encode(yuv) / DctDecoder.decode(yuv) and the DwtDctSvd pair on one host float32 {W}x{H} YUV frame per call "
-                   "(pageable ndarray up, kernels, channel(s) down; includes the caller's yuv.copy()): the path an unmodified reference "
+                   "(pageable ndarray up, kernels, the frame down into the caller's array): the path an unmodified reference "
                    "Embedder takes (video/embedder.py:35).  The batched u8 path is the product's fast path")
     return out
 
@@ -327,6 +337,77 @@ class stdout_to_stderr:
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
+
+
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes():
+    """NUMA node of every AMD GPU of this host in PCI bus order -- the order the HIP runtime enumerates them in -- from sysfs
+    (/sys/class/drm/card*/device/numa_node); -1 where the platform reports none."""
+    import glob
+    import re
+    found = []
+    for dev in glob.glob("/sys/class/drm/card*/device"):
+        if not re.fullmatch(r"card\d+", os.path.basename(os.path.dirname(dev))):
+            continue                                                     # connectors (card0-DP-1) are not devices
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            found.append((os.path.basename(os.path.realpath(dev)), int(open(os.path.join(dev, "numa_node")).read())))
+        except (OSError, ValueError):
+            continue
+    return [node for _, node in sorted(found)]
+
+
+def bind_to_gpu_numa(gpu_of_rank, local_rank):
+    """Bind this process to the cores of its GPU's NUMA node BEFORE anything touches the GPU (the runtime's helper threads
+    inherit the mask).  Ranks whose GPUs share a node split that node's cores between them, so eight ranks on one host do not
+    issue their launches from each other's cores (the shard shape is tests/segment_mark_detect_hls.py:407-412,
+    one independent worker per segment).  gpu_of_rank: HIP device index of every local rank.  Never fatal: a host that does
+    not expose the topology leaves the process where the launcher put it."""
+    info = dict(bound=False)
+    try:
+        nodes = gpu_numa_nodes()
+        vis = None
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):       # device i of the process = entry i of the list
+            text = os.environ.get(var, "")
+            if text and all(x.strip().isdigit() for x in text.split(",")):
+                ids = [int(x) for x in text.split(",")]
+                vis = ids if vis is None else [vis[i] for i in ids]
+        phys = [(vis[g] if vis else g) for g in gpu_of_rank]
+        node = nodes[phys[local_rank]]
+        info.update(gpu=phys[local_rank], numa_node=node, gpus_seen=len(nodes))
+        if node < 0:
+            info["note"] = "the GPU reports no NUMA node"
+            return info
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) & allowed)
+        peers = [r for r in range(len(phys)) if nodes[phys[r]] == node]
+        per = len(cpus) // max(len(peers), 1)
+        mine = cpus[peers.index(local_rank) * per:(peers.index(local_rank) + 1) * per] if per >= 2 else cpus
+        if not mine:
+            info["note"] = "no core of that node in this process's affinity mask"
+            return info
+        os.sched_setaffinity(0, mine)
+        info.update(bound=True, cpus=f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine)),
+                    n_cpus=len(mine), ranks_on_node=len(peers))
+    except Exception as exc:
+        info["error"] = repr(exc)
+    return info
+
+
+def inject_failure(where, rank):
+    """Test hook (tests/test_gpu_parity.py): OFMK_BENCH_INJECT_FAILURE="<rank>:<where>" raises in that rank at that point."""
+    want = os.environ.get("OFMK_BENCH_INJECT_FAILURE", "")
+    if want and want == f"{rank}:{where}":
+        raise RuntimeError(f"injected failure in rank {rank} at {where}")
 
 
 def launch_ranks(a):
@@ -367,6 +448,11 @@ def main():
         raise SystemExit("--emulate-world needs --gpus 1 (it rehearses rank 0 of an M-rank job on ONE GPU)")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)
+    # placement first: nothing has touched the GPU yet (no torch import, no HIP call)
+    env_world, env_local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    n_local = int(os.environ.get("LOCAL_WORLD_SIZE", env_world))
+    placement = dict(bound=False, note="--no-bind") if a.no_bind else \
+        bind_to_gpu_numa([0] * n_local if a.single_device else list(range(n_local)), env_local)
     import torch
     import torch.distributed as dist
     from offmark import _hip
@@ -521,7 +607,7 @@ def main():
             super().__init__(dev, j.n, L, j.seg_global,
                              make_engine=lambda: DctEngine(device=dev, chunk_frames=self.chunk, opts=opts_plain, tile_order=a.tile_order),
                              make_out=lambda: torch.empty_like(src) if j.mode == "embed_detect" else None,
-                             issue=self.issue_step, lanes=n_lanes, group=group, graph=graph, gather=self.gather_rows)
+                             issue=self.issue_step, lanes=n_lanes, group=group, graph=graph, gather=self.gather_rows, equal_shards=j.equal)
             if emulate:        # the gathered buffer of an M-rank job, rank-major [M, G, n, L]: the other ranks' parts are pre-filled
                 ew = j.shard_world
                 per_rank = torch.from_numpy(j.expected_rows).to(dev).view(ew, 1, j.n, L).expand(ew, self.G, j.n, L).contiguous()
@@ -566,7 +652,7 @@ def main():
 
         def prepare(self):
             """One-time set-up, not a workload step: allocate the scratch for the chunk size in use, let the runtime load the code
-            objects and the engine calibrate its tile order (one full-size pass, so that profiles only ever see full-size launches),
+            objects (one full-size pass, so that profiles only ever see full-size launches; --tile-order calibrate measures here),
             exercise the download path, capture the G-step graphs when asked.  Even --warmup 0 then times steady-state steps."""
             if self.j.n:
                 for e in self.engines():
@@ -654,10 +740,19 @@ def main():
     setup_gap_ms = round(1e3 * (time.perf_counter() - cal_at), 2) if cal_at else None     # host time from the calibration's last launch to here
     if a.warmup:
         runner.run(a.warmup)                                # ... and so do the warm-up steps: they are the timed steps' twins
+    inject_failure("timed", rank)
     elapsed, votes, last_size = runner.timed(a.steps)
-    shipped_order = lanes[0].eng.tile_order                  # what the timed region ran with (later side measurements may calibrate)
+    shipped_order = lanes[0].eng.tile_order                  # what the timed region ran with
     shipped_info = lanes[0].eng.tile_order_info
     host_ms = {k: round(1e3 * v / a.steps, 4) for k, v in runner.host_s.items()}
+    ranks_bound = int(bool(placement.get("bound")))
+    if grouped:          # the slowest rank's host sets the pace: MAX over ranks (every rank takes part, unconditionally)
+        hm = torch.tensor([host_ms["enqueue"], host_ms["vote"], float(ranks_bound)], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        hs = hm.clone()
+        dist.all_reduce(hm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hs, op=dist.ReduceOp.SUM)
+        host_ms = dict(enqueue=round(float(hm[0]), 4), vote=round(float(hm[1]), 4), over="max over ranks")
+        ranks_bound = int(round(float(hs[2])))
     runner.set_opts(opts_plain)
     kern, series = None, []
     if not a.no_kernel_events:
@@ -689,6 +784,25 @@ def main():
         payload_ok = votes_ok
 
     extra = {}
+    # Side measurements.  One GPU: each is guarded, a failure is reported inside the line.  N > 1: off unless --side-measurements
+    # (every one of them is paid N-fold under barriers), and NEVER guarded: a rank that swallowed an exception would fall out of
+    # step with the others' collectives and leave them in a barrier until the driver's time limit -- the exception propagates,
+    # the rank exits non-zero, the launcher ends the job, no line is printed.
+    sides_on = not a.no_extras and (world == 1 or a.side_measurements)
+
+    class side:
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            inject_failure(self.name, rank)
+
+        def __exit__(self, et, ev, tb):
+            if et is None or not issubclass(et, Exception) or world > 1:
+                return False
+            extra[self.name] = dict(error=repr(ev))
+            return True
+
     if cfg == 5 and world == 1 and not a.no_extras and n and not emu:
         e0 = lanes[0].eng
         det = (lambda x: e0.detect(x, L, alpha=a.alpha)[0]) if a.codec == "dct" else (lambda x: e0.svd_detect(x, L, scale=15, blk=a.blk)[0])
@@ -697,39 +811,40 @@ def main():
     # the same K steps once more, straight after the timed region.  `value` is the contract's figure (W warm-up steps after
     # idle, then K steps: with a short K that sits on the device's clock ramp); this one is the rate the device settles at.
     if not a.no_extras:
+        inject_failure("second_pass", rank)
         el_b, v_b, sz_b = runner.timed(a.steps)
         extra["value_second_pass"] = round((n if emu else job.total_frames) * a.steps / el_b, 1)
         extra["second_pass"] = dict(steps=a.steps, ms_per_step=round(1e3 * el_b / a.steps, 4), votes_ok=runner.votes_ok(v_b, sz_b),
                                     note="the same K steps again straight after the timed region (no event pairs on the launches)")
 
     # ---- the fused mark kernel in BOTH tile orders, same K steps, interleaved in this process ----
-    if a.codec == "dct" and mode == "embed_detect" and not planar and not a.separate_detect and not a.no_extras and n and not a.no_kernel_events:
+    if a.codec == "dct" and mode == "embed_detect" and not planar and not a.separate_detect and sides_on and n and not a.no_kernel_events:
         try:
-            shipped, info = shipped_order, shipped_info
-            t_ab = _hip.Timing(2 * n_chunks * a.steps + 16, 1 << _hip.TIMING_KINDS.index("mark_fused"))
-            runner.set_opts(t_ab.opts(flags))
-            res = {"xcd": [], "linear": []}
-            for order in ("xcd", "linear", "linear", "xcd"):
-                runner.set_order(order)
-                runner.run(1)
-                torch.cuda.synchronize()
-                t_ab.collect()
-                el_o, _, _ = runner.timed(a.steps)
-                kk = t_ab.collect()["mark_fused"]
-                res[order].append((1e3 * el_o / a.steps, kk["ms_total"] / max(kk["launches"], 1)))
-            runner.set_order(a.tile_order)
-            runner.set_opts(opts_plain)
-            t_ab.close()
-            extra["mark_order"] = dict(
-                xcd_ms=round(float(np.mean([k for _, k in res["xcd"]])), 5), linear_ms=round(float(np.mean([k for _, k in res["linear"]])), 5),
-                xcd_step_ms=round(float(np.min([s_ for s_, _ in res["xcd"]])), 4), linear_step_ms=round(float(np.min([s_ for s_, _ in res["linear"]])), 4),
-                shipped=shipped, mode=a.tile_order, calibration={k: v for k, v in info.items() if k not in ("mode", "in_use")},
-                xcc_deal=engine_mod.probe_xcc_deal(dev),
-                note=f"fused mark kernel, average launch duration over 2 x {a.steps} steps per order, run xcd / linear / linear / xcd after the "
-                     "timed region (*_step_ms: the faster of an order's two passes -- a pass now and then catches a one-off host stall of tens of "
-                     "milliseconds); `shipped` is what the timed region used (auto = the engine's calibration at set-up)")
-        except Exception as exc:
-            extra["mark_order"] = dict(error=repr(exc))
+            with side("mark_order"):
+                shipped, info = shipped_order, shipped_info
+                t_ab = _hip.Timing(2 * n_chunks * a.steps + 16, 1 << _hip.TIMING_KINDS.index("mark_fused"))
+                runner.set_opts(t_ab.opts(flags))
+                res = {"xcd": [], "linear": []}
+                for order in ("xcd", "linear", "linear", "xcd"):
+                    runner.set_order(order)
+                    runner.run(1)
+                    torch.cuda.synchronize()
+                    t_ab.collect()
+                    el_o, _, _ = runner.timed(a.steps)
+                    kk = t_ab.collect()["mark_fused"]
+                    res[order].append((1e3 * el_o / a.steps, kk["ms_total"] / max(kk["launches"], 1)))
+                t_ab.close()
+                extra["mark_order"] = dict(
+                    xcd_ms=round(float(np.mean([k for _, k in res["xcd"]])), 5), linear_ms=round(float(np.mean([k for _, k in res["linear"]])), 5),
+                    xcd_step_ms=round(float(np.min([s_ for s_, _ in res["xcd"]])), 4), linear_step_ms=round(float(np.min([s_ for s_, _ in res["linear"]])), 4),
+                    shipped=shipped, mode=a.tile_order, policy=info.get("policy"),
+                    policy_detail={k: v for k, v in info.items() if k not in ("mode", "in_use", "policy")},
+                    xcc_deal=engine_mod.probe_xcc_deal(dev),
+                    note=f"fused mark kernel, average launch duration over 2 x {a.steps} steps per order, run xcd / linear / linear / xcd after the "
+                         "timed region (*_step_ms: the faster of an order's two passes -- a pass now and then catches a one-off host stall of tens of "
+                         "milliseconds); `shipped` is what the timed region used and `policy` how it was chosen (static rule = the library's rule on "
+                         "the bytes per launch, no measurement; calibrated = --tile-order calibrate; forced = --tile-order xcd / linear)")
+        finally:
             runner.set_order(a.tile_order)
             runner.set_opts(opts_plain)
 
@@ -761,25 +876,24 @@ def main():
     # step's analyze beside the other's mark+verify, launch gaps and kernel tails filled.  Reported next to `value`, which stays
     # single-stream: under concurrency a kernel's launch duration includes the time it shares the device, so the roofline object
     # (bytes per launch / launch duration) would no longer describe the kernel.
-    if cfg in (2, 3) and a.codec == "dct" and a.streams == 1 and not a.no_extras and n and not planar and not emu:
+    if cfg in (2, 3) and a.codec == "dct" and a.streams == 1 and sides_on and n and not planar and not emu:
         try:
-            runner.add_lane(torch.cuda.Stream())
-            lanes[1].eng.workspace(H, W, lanes[1].eng._chunk(n, H, W))
-            runner.run(2)
-            el_t, v_t, sz_t = runner.timed(a.steps)
-            extra["value_two_streams"] = round(job.total_frames * a.steps / el_t, 1)
-            extra["two_streams"] = dict(steps=a.steps, ms_per_step=round(1e3 * el_t / a.steps, 4),
-                                        path_frac_of_peak=round(job.total_frames * a.steps / el_t * 9 * H * W / 1e9 / (HBM_PEAK_GBPS * world), 4),
-                                        votes_ok=runner.votes_ok(v_t, sz_t),
-                                        note="the same K steps, consecutive steps on two HIP streams (python bench.py --streams 2 times this form)")
-        except Exception as exc:                               # e.g. no room for the second output buffer
-            extra["two_streams"] = dict(error=repr(exc))
+            with side("two_streams"):                            # may fail for want of room for the second output buffer
+                runner.add_lane(torch.cuda.Stream())
+                lanes[1].eng.workspace(H, W, lanes[1].eng._chunk(n, H, W))
+                runner.run(2)
+                el_t, v_t, sz_t = runner.timed(a.steps)
+                extra["value_two_streams"] = round(job.total_frames * a.steps / el_t, 1)
+                extra["two_streams"] = dict(steps=a.steps, ms_per_step=round(1e3 * el_t / a.steps, 4),
+                                            path_frac_of_peak=round(job.total_frames * a.steps / el_t * 9 * H * W / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                                            votes_ok=runner.votes_ok(v_t, sz_t),
+                                            note="the same K steps, consecutive steps on two HIP streams (python bench.py --streams 2 times this form)")
         finally:
             if len(lanes) > 1:
                 torch.cuda.synchronize()
                 lanes.pop()
 
-    side_ok = cfg == 2 and a.codec == "dct" and not a.separate_detect and not a.no_extras and not planar and not emu
+    side_ok = cfg == 2 and a.codec == "dct" and not a.separate_detect and sides_on and not planar and not emu
     # second figure of the same line: SURVEY 8d config 2 read literally (embed, then the stand-alone detect)
     if side_ok:
         runner.set_opts(_hip.Opts(_hip.F_SEPARATE_DETECT, 0, None))
@@ -800,6 +914,32 @@ def main():
             pm = step()
         runner.fence()
         return time.perf_counter() - t0, pm
+
+    # the two operations the reference's drivers actually perform, each alone (VERDICT r4 missing 2): tests/mark.py:18-40 =
+    # Embedder.__mark_frame per frame (video/embedder.py:33-39) -> embed only, 6 B/px algorithmic (the frame is read twice: the
+    # luminance mask needs the frame mean first, so 9 B/px really move); tests/detect.py:17-31 = Extractor.__check_frame per frame
+    # (video/extractor.py:30-34) -> detect + payloads, 3 B/px
+    if cfg in (2, 3) and a.codec == "dct" and mode == "embed_detect" and not planar and sides_on and n and not emu:
+        with side("embed_only"):
+            e0, k5 = lanes[0].eng, max(3, min(a.steps, 20))
+            marked = lanes[0].out
+            pay5 = torch.empty((n, L), dtype=torch.uint8, device=dev)
+
+            def embed_step():
+                return e0.embed(job.frames, job.wm_dev, alpha=a.alpha, wm_row=job.rows_dev, out=marked)
+
+            def detect_step():
+                return e0.payloads(e0.detect(marked, L, alpha=a.alpha)[0], N, perm_dev, out=pay5)
+            for key, step, bpp_alg, what in (("embed_only", embed_step, 6, "embed alone: analyze + mark (no verify), marked frames written"),
+                                             ("detect_only", detect_step, 3, "detect + payloads of the marked frames alone: analyze, finalize, payload kernel")):
+                el5, res5 = side_rate(step, k5)
+                rate = world * n * k5 / el5
+                extra[key] = dict(value=round(rate, 1), unit="frames/s", steps=k5, ms_per_step=round(1e3 * el5 / k5, 4),
+                                  algorithmic_bytes_per_frame=bpp_alg * H * W, algorithmic_GBps=round(rate * bpp_alg * H * W / 1e9, 1),
+                                  frac_of_peak=round(rate * bpp_alg * H * W / 1e9 / (HBM_PEAK_GBPS * world), 4), note=what)
+                if key == "detect_only":
+                    extra[key]["payload_ok"] = bool((res5.cpu().numpy() == want_mine).all())
+            del pay5
 
     # planar 4:2:0 frames through the same step, HBM-resident: what the fused ingest/egress costs or saves
     if side_ok and H % 8 == 0 and W % 8 == 0:
@@ -927,6 +1067,9 @@ def main():
     copy_gbps = probe(lambda: _hip.check(lib.ofmk_hbm_copy(probe_src.data_ptr(), probe_dst.data_ptr(), nbytes, s)), 2 * nbytes)
     read_gbps = probe(lambda: _hip.check(lib.ofmk_hbm_read(probe_src.data_ptr(), nbytes, sink.data_ptr(), s)), nbytes)
 
+    for key, ceil_name, ceil in (("embed_only", "frac_of_measured_copy", copy_gbps), ("detect_only", "frac_of_measured_read", read_gbps)):
+        if key in extra and "algorithmic_GBps" in extra[key]:
+            extra[key][ceil_name] = round(extra[key]["algorithmic_GBps"] / (ceil * world), 4)
     units = n if emu else job.total_frames                  # emulation: `value` is what this ONE GPU really processed
     fps = units * a.steps / elapsed
     frame_bytes = 3 * H * W
@@ -1016,6 +1159,7 @@ def main():
                    "codec": a.codec, "frames_per_gpu": n, "payload_bits": L, "alpha": a.alpha,
                    "chunk_frames": chunk, "chunks_per_step": n_chunks, "steps_per_host_iteration": G, "hipgraph": bool(use_graph),
                    "tile_order": shipped_order if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
+                   "tile_order_policy": shipped_info.get("policy") if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")
                    if a.codec == "dct" else ("stand-alone kernel" if mode == "detect" else "fused into the embed kernel"),
                    "sharding": f"{'frames' if cfg in (2, 3) else 'segments'}, {sw} rank(s), one RCCL all-gather of payloads"},
@@ -1029,7 +1173,8 @@ def main():
         "collective": {"backend": ("rccl" if a.backend == "nccl" else a.backend) if grouped else None, "ranks": ranks_seen,
                        "self_launched": bool(os.environ.get("OFMK_BENCH_SELF_LAUNCHED"))},
         "rccl_ranks": ranks_seen if (grouped and a.backend == "nccl") else None,
-        "host_ms_per_step": host_ms,            # rank 0's CPU time issuing a step / voting on one; must stay < ms_per_step
+        "host_ms_per_step": host_ms,            # CPU time issuing a step / voting on one (N > 1: the slowest rank's); must stay < ms_per_step
+        "placement": dict(placement, ranks_bound=ranks_bound),
         "setup_ms_between_calibration_and_warmup": setup_gap_ms,
         "cpu_baseline": None,
     }
@@ -1051,4 +1196,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception:
+        # N > 1: this rank must not linger (its peers are inside collectives that will never complete): report, leave at once with a
+        # failure code, and let the launcher end the others -- no interpreter shutdown that could wait on a communicator
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            os._exit(1)
+        raise SystemExit(1)

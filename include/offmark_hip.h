@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OFMK_ABI_VERSION 4
+#define OFMK_ABI_VERSION 5
 
 #define OFMK_OK            0
 #define OFMK_E_ARG        -1   /* null pointer / non-positive size / H or W < 8 */
@@ -51,7 +51,7 @@ typedef struct ofmk_timing ofmk_timing;     /* opaque, see ofmk_timing_create */
 typedef struct ofmk_opts {
     uint32_t flags;          /* OFMK_F_*; unknown bits are rejected (OFMK_E_ARG) */
     uint32_t xcds;           /* XCDs the XCD-aware tile order assumes: 0 = 8 (MI355X, SPX mode), 1 = linear order, > 64 rejected.
-                                ABI 3 called this word `reserved` and required 0: an ABI-3 caller gets ABI 3's behaviour */
+                                ABI 3 called this word `reserved` and required 0 */
     ofmk_timing *timing;     /* NULL = launches carry no events */
 } ofmk_opts;
 /* ofmk_embed_detect_rgb8: embed, then detect the written frames with the stand-alone detect kernels
@@ -59,15 +59,18 @@ typedef struct ofmk_opts {
  * (9 B/px).  Same results bit for bit. */
 #define OFMK_F_SEPARATE_DETECT 1u
 /* Tile order of the frame-WRITING DCT kernel (ofmk_embed_rgb8, ofmk_embed_detect_rgb8, ofmk_stage_mark_rgb8).  The kernel is
- * one linear grid of 48 KiB tiles; the hardware deals consecutive workgroups round-robin to the XCDs.  Default: XCD-aware
- * order, every XCD walks one contiguous 1/xcds of the batch (tile = (L % xcds) * ceil(G / xcds) + L / xcds); with this flag:
- * tile = workgroup index.  A pure permutation of the work: results are identical bit for bit either way; which one is
- * faster differs from box to box by a few per cent (BENCH_r02 / r03), so the Python engine picks it per device with a
- * calibration (offmark/engine.py: calibrate_tile_order) and bench.py reports both.  The read-only and one-pass kernels
- * always run in linear order (measured faster there).  The reference has no counterpart: its loop is one frame at a
- * time (src/offmark/video/embedder.py:18-31). */
+ * one linear grid of 48 KiB tiles; the hardware deals consecutive workgroups round-robin to the XCDs.  XCD-aware order: every XCD walks one contiguous 1/xcds of the launch's frames (tile = (L % xcds) * ceil(G / xcds)
+ * + L / xcds); linear order: tile = workgroup index.  A pure permutation of the work: results are identical bit for bit either
+ * way.  DEFAULT (neither flag, since ABI 5): a static rule on the launch's size -- XCD-aware when the launch reads at least
+ * OFMK_XCD_TILES_MIN_BYTES of frames (192 frames of 1080p), linear below -- which is what interleaved A/B runs on MI355X say
+ * (large launches: XCD-aware wins by 1.5-3.4 % or ties; 48-96 frames of 1080p: linear wins by 1-4 %; profiles/r4_mark_fused_pass.txt).
+ * The two flags force an order (a caller that has measured its own box: offmark/engine.py calibrate_tile_order); both at once
+ * are rejected.  ABI 4 defaulted to the XCD-aware order at every size.  The read-only and one-pass kernels always run in linear
+ * order (measured faster there).  The reference has no counterpart: its loop is one frame at a time
+ * (src/offmark/video/embedder.py:18-31). */
 #define OFMK_F_LINEAR_TILES 2u
-
+#define OFMK_F_XCD_TILES 4u
+#define OFMK_XCD_TILES_MIN_BYTES 1194393600ull      /* 192 x 1080 x 1920 x 3 */
 /* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
  * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to
  * what fits.  Bigger chunks are faster (fewer launches, shorter tails): keeping a chunk resident

@@ -36,9 +36,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
                 and ("ofmk" in l or " g_" in l) and "(" not in l          # "name(args)" = a kernel's launch handle
                 and "g_err" not in l and "guard variable" not in l]
     assert not writable, writable
-    assert lib.ofmk_version() == _hip.ABI_VERSION == 4
+    assert lib.ofmk_version() == _hip.ABI_VERSION == 5
     # pure host-side entry points are safe to call without a GPU
-    assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 32 * 8 + 4096
+    assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 127 * 8 + 4096      # records + delta, 2 x 127 per-tile partial sums
     assert lib.ofmk_workspace_bytes(0, 1080, 1920) == 0 and lib.ofmk_workspace_bytes(1, 4, 1920) == 0
 
 

@@ -184,3 +184,67 @@ def test_bench_starts_its_own_ranks_and_relays_their_failure():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "local_rank: 1" in r.stderr or "rank      : 1" in r.stderr          # two ranks were really started
+
+
+def test_step_pipeline_refuses_grouped_steps_over_ragged_shards():
+    """with group > 1 the gathered layout is [rank][step][n] with ONE n for every rank; ragged shards (8 segments over
+    3 ranks: 3 + 3 + 2) or an empty shard would mix steps and segments in the vote without any error.  The constructor says so
+    before it touches a device (this runs without a GPU)."""
+    from offmark.dist.steps import StepPipeline
+    seg = np.repeat(np.arange(8), 4)                       # 8 segments x 4 frames over 3 ranks: this rank holds 3 segments = 12 rows
+    for kwargs in (dict(n=12, equal_shards=False), dict(n=0, equal_shards=True), dict(n=5, equal_shards=True)):
+        with pytest.raises(ValueError, match="equal, non-empty shards"):
+            StepPipeline("cpu", L=8, segment_ids=seg, make_engine=None, make_out=None, issue=None, group=4, **kwargs)
+
+
+def test_bench_placement_helpers_without_a_gpu(tmp_path, monkeypatch):
+    """bench.py binds every rank to its GPU's NUMA-local cores before anything touches the GPU.  Host logic
+    only: the cpulist parser, the split of one node's cores between the ranks that share it, and that a host which exposes no
+    topology leaves the process alone instead of failing the run."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    assert bench._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and bench._cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    try:
+        cores = sorted(before)
+        monkeypatch.setattr(bench, "gpu_numa_nodes", lambda: [0, 0, -1])
+        real_open = open
+
+        def fake_open(path, *a, **k):
+            if str(path) == "/sys/devices/system/node/node0/cpulist":
+                import io
+                return io.StringIO(",".join(map(str, cores)))
+            return real_open(path, *a, **k)
+        monkeypatch.setattr("builtins.open", fake_open)
+        monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+        monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+        got, masks = [], []
+        for r in (0, 1):                                    # (each rank is its own process in a real run: undo the first binding)
+            os.sched_setaffinity(0, before)
+            got.append(bench.bind_to_gpu_numa([0, 1, 2], r))
+            masks.append(os.sched_getaffinity(0))
+        if len(cores) >= 4:                                 # two ranks on node 0: disjoint halves of its cores
+            half = len(cores) // 2
+            assert got[0]["bound"] and got[1]["bound"] and got[0]["ranks_on_node"] == 2 and got[0]["n_cpus"] == half
+            assert masks == [set(cores[:half]), set(cores[half:2 * half])]
+        os.sched_setaffinity(0, before)
+        none = bench.bind_to_gpu_numa([0, 1, 2], 2)         # a GPU that reports no node
+        assert not none["bound"] and "no NUMA node" in none["note"] and os.sched_getaffinity(0) == before
+        monkeypatch.setattr(bench, "gpu_numa_nodes", lambda: [])
+        assert not bench.bind_to_gpu_numa([0], 0)["bound"]   # no topology at all: an error text, no exception
+    finally:
+        os.sched_setaffinity(0, before)
+    # the failure-injection hook of the N > 1 tests
+    monkeypatch.setenv("OFMK_BENCH_INJECT_FAILURE", "1:second_pass")
+    bench.inject_failure("second_pass", 0)
+    with pytest.raises(RuntimeError, match="rank 1 at second_pass"):
+        bench.inject_failure("second_pass", 1)

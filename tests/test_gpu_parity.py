@@ -429,7 +429,8 @@ def test_tile_orders_are_bit_identical_and_the_xcc_probe_reads_the_deal(eng):
     """The fused mark kernel's tile order (ofmk_opts: OFMK_F_LINEAR_TILES, xcds) is a pure permutation of the workgroups:
     linear, XCD-aware over 8 and over other XCD counts (padding workgroups, a count that does not divide the grid) must give
     the same marked frames, counts and bits.  ofmk_probe_xcc must report a sane deal; the calibration must pick one of the
-    two orders from measured durations and every engine on the device must then use it."""
+    two orders from measured durations and every engine on the device must then use it (r4 item 1: only on
+    request, per size bucket, with a margin -- the default is the library's static rule)."""
     import torch
     from offmark import _hip, engine as E
     from offmark.synthetic import synthetic_frames
@@ -440,7 +441,7 @@ def test_tile_orders_are_bit_identical_and_the_xcc_probe_reads_the_deal(eng):
     rows = (np.arange(n) % 2).astype(np.int32)
     ref = None
     for flags, xcds in ((0, 0), (_hip.F_LINEAR_TILES, 0), (0, 1), (0, 4), (0, 7), (0, 8), (0, 64), (_hip.F_SEPARATE_DETECT, 5)):
-        e = type(eng)(opts=_hip.Opts(flags, xcds, None), tile_order="xcd")
+        e = type(eng)(opts=_hip.Opts(flags | (0 if flags & _hip.F_LINEAR_TILES else _hip.F_XCD_TILES), xcds, None))
         got = e.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
         plain = e.embed(frames, wm, wm_row=rows)
         assert torch.equal(plain, got[0])
@@ -456,21 +457,30 @@ def test_tile_orders_are_bit_identical_and_the_xcc_probe_reads_the_deal(eng):
     deal = E.probe_xcc_deal()
     assert 1 <= deal["xcds"] <= 16 and len(deal["ids_by_residue"]) == deal["xcds"] and 0.0 < deal["round_robin_fraction"] <= 1.0
     print("xcc deal:", deal)
-    # calibration on a batch big enough to time: picks an order from its own measurement, kept per device AND launch shape
+    # default policy: no measurement -- the library's static rule on the launch size (small launches linear, large ones XCD-aware)
     big = synthetic_frames(48, 1080, 1920, seed=78)
     wm_big = orc.shuffle_generate(P8, (32400,), 0)[None]
-    info = type(eng)().calibrate_tile_order(big, force=True, min_ms=60.0)
-    assert info["order"] in ("xcd", "linear") and info["xcd_ms"] > 0 and info["linear_ms"] > 0 and info["frames_per_launch"] == 48
-    assert (info["order"] == "linear") == (info["linear_ms"] < info["xcd_ms"] or not info["round_robin"])
     auto = type(eng)()
-    a = auto.embed_detect(big, wm_big, L=8)                           # same shape: uses the calibrated order, does not calibrate again
-    assert auto.tile_order == info["order"] and auto.tile_order_info["xcd_ms"] == info["xcd_ms"]
-    fixed = type(eng)(tile_order="linear" if info["order"] == "xcd" else "xcd")
-    b = fixed.embed_detect(big, wm_big, L=8)
-    assert fixed.tile_order != auto.tile_order
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    small = auto.embed_detect(big[:8], wm_big, L=8)                   # another shape, too small to calibrate: the default order
-    assert auto.tile_order == "xcd" and torch.equal(small[0], a[0][:8])
+    a = auto.embed_detect(big, wm_big, L=8)
+    assert auto.tile_order == "linear" and auto.tile_order_info["policy"] == "static rule"       # 48 frames of 1080p < 192
+    assert E.static_tile_order(192 * 1080 * 1920 * 3) == "xcd" and E.static_tile_order(191 * 1080 * 1920 * 3) == "linear"
+    for forced in ("xcd", "linear"):
+        b = type(eng)(tile_order=forced).embed_detect(big, wm_big, L=8)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    both = _hip.Opts(_hip.F_LINEAR_TILES | _hip.F_XCD_TILES, 0, None)
+    assert lib.ofmk_embed_rgb8(frames.data_ptr(), ref[0].data_ptr(), n, H, W, cuda(wm.astype(np.uint8)).data_ptr(), 2, None, 20.0, 0,
+                               ws.data_ptr(), ws.numel(), _hip.current_stream(), both) == -1
+    # explicit calibration on a batch big enough to time: measured durations, a 1 % margin to leave the static rule's order,
+    # kept per device and SIZE BUCKET, used by every engine of the device from then on
+    info = type(eng)().calibrate_tile_order(big, force=True, min_ms=60.0)
+    assert info["order"] in ("xcd", "linear") and info["xcd_ms"] > 0 and info["linear_ms"] > 0 and info["static_rule"] == "linear"
+    assert info["bucket_log2"] == E.order_bucket(48 * 1080 * 1920 * 3)
+    assert (info["order"] == "xcd") == (not info["tie"]) and (info["tie"] or info["xcd_ms"] < 0.99 * info["linear_ms"])
+    again = type(eng)()
+    c = again.embed_detect(big[:44], wm_big, L=8)                     # another batch length, same bucket (2^28 <= bytes < 2^29): the record is used, nothing is measured
+    assert again.tile_order == info["order"] and again.tile_order_info["policy"] == "calibrated"
+    assert torch.equal(c[0], a[0][:44])
+    E._TILE_ORDER.clear()
     print("tile order calibration:", info)
 
 
@@ -1136,12 +1146,17 @@ def test_bench_configs_run_at_one_gpu(config, extra):
         mo = line["mark_order"]
         assert mo["xcd_ms"] > 0 and mo["linear_ms"] > 0 and mo["shipped"] in ("xcd", "linear") and mo["xcc_deal"]["xcds"] >= 1
         assert line["config"]["tile_order"] == mo["shipped"]          # what the TIMED region used
+        assert mo["policy"] == line["config"]["tile_order_policy"] == "static rule"       # the default measures nothing
     if config == 5:        # BASELINE configs[4]: the attack suite is reported next to the line; clean and noisy leaks must resolve
         assert line["config"]["codec"] == ("dwtdctsvd" if "dwtdctsvd" in extra else "dct")      # --codec is honoured
         assert ("svd" in line["roofline"]["kernel"]) == ("dwtdctsvd" in extra)
         atk = line["attacks"]
         assert atk["none"]["copies_recovered"] and atk["none"]["payload_ber"] == 0 and atk["noise_sigma2"]["copies_recovered"]
         assert all(k in atk for k in ("scale_2_3_and_back", "crop16_and_resize_back", "jpeg_q95_420", "jpeg_q75_420"))
+    if config in (2, 3):   # the two operations mark.py / detect.py perform, each alone (VERDICT r4 missing 2)
+        eo, do = line["embed_only"], line["detect_only"]
+        assert eo["value"] > 0 and 0 < eo["frac_of_peak"] < 1 and eo["frac_of_measured_copy"] > 0 and eo["algorithmic_bytes_per_frame"] % 6 == 0
+        assert do["value"] > 0 and 0 < do["frac_of_peak"] < 1 and do["frac_of_measured_read"] > 0 and do["payload_ok"]
     if config == 2:
         assert line["value_separate_detect"] > 0 and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["planar_i420"]["value"] > 0
@@ -1228,7 +1243,7 @@ def test_bench_two_ranks_gloo_on_one_device(config, launcher):
                  "--master-port", str(port)]
     cmd = head + [os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
                   "--config", str(config), "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
-                  "--no-cpu-baseline"] + (["--no-extras"] if config != 2 else [])      # config 2: the side measurements run on every rank too
+                  "--no-cpu-baseline"] + (["--no-extras"] if config != 2 else ["--side-measurements"])      # config 2: the side measurements run on every rank too
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     out_lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
@@ -1238,9 +1253,46 @@ def test_bench_two_ranks_gloo_on_one_device(config, launcher):
     assert line["collective"] == {"backend": "gloo", "ranks": 2, "self_launched": launcher == "self"} and line["rccl_ranks"] is None
     assert line["config"]["frames_per_gpu"] == (8 if config == 2 else 4 * 8)      # config 4: 8 segments / 2 ranks x 8 frames
     assert line["config"]["steps_per_host_iteration"] == 3 and line["config"]["hipgraph"]   # small shards: the three steps are ONE graph, gathered and voted on together
+    assert line["host_ms_per_step"]["over"] == "max over ranks" and "placement" in line
     if config == 2:
         assert line["value_second_pass"] > 0 and line["second_pass"]["votes_ok"] and line["separate_detect"]["votes_ok"]
         assert line["planar_i420"]["payload_ok"] and line["dwtdctsvd"]["payload_ok"]
+
+
+@pytest.mark.parametrize("where,flags", [("second_pass", []), ("mark_order", ["--side-measurements"]), ("timed", [])])
+def test_bench_rank_failure_ends_the_whole_job(where, flags):
+    """at N > 1 an exception in ONE rank (here injected into rank 1: in the timed steps, in the
+    second pass, inside a side measurement that used to sit in a try/except) must end the WHOLE job quickly with a non-zero exit
+    and no JSON line -- never leave the other rank in a barrier until somebody's time limit.  Default N > 1 runs also skip the
+    side measurements: N = 2 must take no longer than 1.5 x the N = 1 run of the same arguments."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--backend", "gloo", "--single-device", "--height", "240", "--width", "320", "--frames", "8", "--steps", "3", "--warmup", "1",
+            "--no-cpu-baseline", *flags]
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *args], capture_output=True, text=True, timeout=300,
+                       env=dict(env, OFMK_BENCH_INJECT_FAILURE=f"1:{where}"), cwd=root)
+    took = time.perf_counter() - t0
+    assert r.returncode != 0 and took < 60, (r.returncode, took, r.stderr[-1500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[-500:]
+    assert f"injected failure in rank 1 at {where}" in r.stderr
+    if where == "second_pass":          # the healthy twin of the same command, and the one-GPU run of the same arguments
+        t0 = time.perf_counter()
+        ok2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *args], capture_output=True, text=True,
+                             timeout=600, env=env, cwd=root)
+        t2 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ok1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *args[3:]], capture_output=True, text=True,
+                             timeout=600, env=env, cwd=root)
+        t1 = time.perf_counter() - t0
+        assert ok2.returncode == 0 and ok1.returncode == 0, (ok2.stderr[-1500:], ok1.stderr[-1500:])
+        line2 = [l for l in ok2.stdout.splitlines() if l.startswith("{")]
+        assert len(line2) == 1 and "mark_order" not in line2[0] and "second_pass" in line2[0]       # N > 1 default: value + second pass only
+        print(f"bench wall time: N=2 (gloo, one device) {t2:.1f} s, N=1 {t1:.1f} s")
+        assert t2 < 1.5 * t1, (t2, t1)
 
 
 def test_c_host_program_over_the_abi(tmp_path):

@@ -163,7 +163,7 @@ def test_plugin_classes_on_planes(eng):
     assert np.array_equal(got, np.tile(P8, (n, 1)))
     lib = _hip.load()
     ws = eng.workspace(H, W, n)
-    bad = _hip.Opts(8, 0, None)
+    bad = _hip.Opts(64, 0, None)          # an unknown flag bit
     wm = torch.zeros(H * W // 64, dtype=torch.uint8, device="cuda")
     assert lib.ofmk_embed_yuv420(planes.data_ptr(), marked.data_ptr(), 1, n, H, W, wm.data_ptr(), 1, None, 20.0, 0, ws.data_ptr(),
                                  ws.numel(), _hip.current_stream(), bad) == -1

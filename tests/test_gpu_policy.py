@@ -1,0 +1,141 @@
+"""GPU tests of round 5's scheduling and scratch changes (through the C ABI, ctypes):
+
+  * the tile-order policy: a default engine measures nothing, whatever batch lengths it is fed; calibration is opt-in, per size
+    bucket, under a lock, with a margin and a per-process budget;
+  * the frame mean from per-tile partial sums (no zero-fill dispatch, no atomics): stale scratch must never leak into a result,
+    whatever the launch shape (ragged tiles, chunks, sizes that are no multiple of 8).  Oracle for the arithmetic itself:
+    tests/test_gpu_parity.py (CPU oracle and the reference-run golden vectors), which runs on the same kernels.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import offmark_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    from offmark.engine import DctEngine
+    torch.cuda.set_device(0)
+    return DctEngine()
+
+
+def cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _perm(L, key=0):
+    from offmark.degenerator.de_shuffler import DeShuffler
+    return np.asarray(DeShuffler(key=key).set_shape((L,)).payload_idx)
+
+
+@pytest.mark.parametrize("H,W,n,chunk", [(240, 320, 5, None), (360, 648, 37, 7), (30, 44, 9, None), (1080, 1920, 12, 5)])
+def test_stale_scratch_never_reaches_a_result(eng, H, W, n, chunk):
+    """Rounds 1-4 zero-filled the frame-mean accumulators in front of every analyze launch and added into them with atomics.
+    Now every workgroup stores ONE partial sum of its tile's block DCs at [frame][tile] and the consumers add the frame's entries
+    up (integer adds: any order gives the same bits), so nothing is zeroed and nothing may be assumed about the scratch: fill it
+    with garbage of several kinds between calls -- results must not move.  dct_encoder.py:54-56 (the frame-global mean)."""
+    import torch
+    from offmark.synthetic import synthetic_frames
+    E = type(eng)
+    N = H * W // 64
+    frames = synthetic_frames(n, H, W, seed=600 + H)
+    wm = np.stack([orc.shuffle_generate(P8, (N,), 0), orc.shuffle_generate(1 - P8, (N,), 0)]).astype(np.uint8)
+    rows = (np.arange(n) % 2).astype(np.int32)
+    e = E(chunk_frames=chunk)
+    ref = e.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
+    ref_det = e.detect(ref[0], 8, want_bits=True)
+    ws = e.workspace(H, W, e._chunk(n, H, W))
+    for fill in (0x00, 0xFF, 0xA5, None):
+        if fill is None:
+            ws.random_(0, 256)
+        else:
+            ws.fill_(fill)
+        got = e.embed_detect(frames, wm, L=8, wm_row=rows, want_bits=True)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), fill
+        ws.fill_(0x5A if fill is None else fill ^ 0x3C)
+        det = e.detect(got[0], 8, want_bits=True)
+        assert torch.equal(det[0], ref_det[0]) and torch.equal(det[1], ref_det[1]) and torch.equal(det[0], ref[1]), fill
+    if H >= 64:
+        want = np.where(rows[:, None] == 0, P8, 1 - P8)
+        assert np.array_equal(e.payloads(ref[1], N, _perm(8)).cpu().numpy(), want)
+
+
+def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
+    """VERDICT r4 item 1 / ADVICE r4: round 4's default engine calibrated the tile order on the first large call of every exact
+    launch shape (0.25-0.8 s and ~256 repeats of the caller's call each).  Now: twelve distinct batch lengths >= 33 frames of
+    1080p through a DEFAULT engine cost what they cost through an engine with a forced order -- under 100 ms of hidden time in
+    all -- leave no calibration record, and give the forced engine's results."""
+    import torch
+    from offmark import engine as E
+    from offmark.synthetic import synthetic_frames
+    H, W = 1080, 1920
+    lengths = [33, 34, 36, 40, 47, 48, 64, 96, 100, 192, 193, 200]
+    frames = synthetic_frames(max(lengths), H, W, seed=31)
+    out = torch.empty_like(frames)
+    wm = cuda(orc.shuffle_generate(P8, (1, H * W // 64), 0).astype(np.uint8))
+    perm = cuda(_perm(8).astype(np.int32))
+    E._TILE_ORDER.clear()
+    spent0 = E._CALIBRATION_SPENT_MS[0]
+
+    def run(e):
+        got = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for m in lengths:
+            _, c, _ = e.embed_detect(frames[:m], wm, L=8, out=out[:m])
+            got.append((m, e.tile_order, e.payloads(c, H * W // 64, perm), c))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, got
+
+    forced, default = type(eng)(tile_order="xcd"), type(eng)()
+    for e in (forced, default):                       # allocations, code objects
+        e.embed_detect(frames[:33], wm, L=8, out=out[:33])
+    t_forced, ref = run(forced)
+    t_default, got = run(default)
+    assert not E._TILE_ORDER and E._CALIBRATION_SPENT_MS[0] == spent0
+    assert t_default < t_forced + 0.100, (t_default, t_forced)
+    for (m, order, p, c), (_, _, p_r, c_r) in zip(got, ref):
+        assert order == ("xcd" if m >= 192 else "linear"), (m, order)
+        assert torch.equal(p, p_r) and torch.equal(c, c_r)
+    print(f"12 batch lengths: default engine {1e3 * t_default:.1f} ms, forced order {1e3 * t_forced:.1f} ms")
+
+
+def test_calibrate_mode_is_bucketed_locked_and_budgeted(eng):
+    """tile_order="calibrate" (opt-in): one measurement per (device, kernel, log2 size bucket) -- a second batch length of the
+    same bucket measures nothing --, and none at all once the process's calibration budget is spent."""
+    import torch
+    from offmark import engine as E
+    from offmark.synthetic import synthetic_frames
+    H, W = 1080, 1920
+    frames = synthetic_frames(60, H, W, seed=32)
+    out = torch.empty_like(frames)
+    wm = cuda(orc.shuffle_generate(P8, (1, H * W // 64), 0).astype(np.uint8))
+    E._TILE_ORDER.clear()
+    saved = (E._CALIBRATION_BUDGET_MS, E._CALIBRATION_SPENT_MS[0])
+    try:
+        E._CALIBRATION_SPENT_MS[0] = 0.0
+        e = type(eng)(tile_order="calibrate")
+        a = e.embed_detect(frames[:48], wm, L=8, out=out[:48])[1].clone()
+        assert len(E._TILE_ORDER) == 1 and e.tile_order_info["policy"] == "calibrated"
+        spent = E._CALIBRATION_SPENT_MS[0]
+        assert 0 < spent < 1500
+        e.embed_detect(frames[:60], wm, L=8, out=out[:60])              # 48 and 60 frames share a bucket (2^28 <= bytes < 2^29)
+        assert len(E._TILE_ORDER) == 1 and E._CALIBRATION_SPENT_MS[0] == spent
+        E._TILE_ORDER.clear()
+        E._CALIBRATION_BUDGET_MS = 0.0                                   # budget spent: falls back to the static rule, no stall
+        t0 = time.perf_counter()
+        b = e.embed_detect(frames[:48], wm, L=8, out=out[:48])[1]
+        torch.cuda.synchronize()
+        assert not E._TILE_ORDER and time.perf_counter() - t0 < 0.2 and e.tile_order_info["policy"] == "static rule"
+        assert torch.equal(a, b)
+    finally:
+        E._CALIBRATION_BUDGET_MS, E._CALIBRATION_SPENT_MS[0] = saved
+        E._TILE_ORDER.clear()

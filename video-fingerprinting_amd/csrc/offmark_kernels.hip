@@ -37,6 +37,7 @@
 #include "../../include/offmark_hip.h"
 
 #include "common.hiph"
+#include "readout.hiph"
 #include "dct_kernels.hiph"
 #include "svd_kernels.hiph"
 #include "svd8_kernels.hiph"
@@ -74,7 +75,7 @@ struct Ctx {
     hipStream_t s;
     ofmk_timing *t;
     unsigned flags;
-    int xcds;         // tile order of the frame-writing DCT kernel: 0 = linear, X = XCD-aware over X XCDs (common.hiph: xcd_tile)
+    int xcds;         // XCDs the XCD-aware tile order assumes (common.hiph: xcd_tile); which order a launch uses: tile_xcds()
 };
 constexpr int kDefaultXcds = 8;      // MI355X in SPX mode; ofmk_opts.xcds overrides (ofmk_probe_xcc counts the real ones)
 Ctx make_ctx(void *stream, const ofmk_opts *o) {
@@ -82,9 +83,22 @@ Ctx make_ctx(void *stream, const ofmk_opts *o) {
     c.s = static_cast<hipStream_t>(stream);
     c.t = o ? o->timing : nullptr;
     c.flags = o ? o->flags : 0u;
-    c.xcds = (c.flags & OFMK_F_LINEAR_TILES) ? 0 : (o && o->xcds ? (int)o->xcds : kDefaultXcds);
+    c.xcds = o && o->xcds ? (int)o->xcds : kDefaultXcds;
     if (c.xcds == 1) c.xcds = 0;
     return c;
+}
+
+// Tile order of one launch of the frame-writing DCT kernel (include/offmark_hip.h: OFMK_F_LINEAR_TILES / OFMK_F_XCD_TILES).
+// Without a flag the library decides by a STATIC rule on the bytes of frames the launch reads: XCD-aware from
+// OFMK_XCD_TILES_MIN_BYTES (192 frames of 1080p) up, linear below.  That is what four rounds of interleaved A/B say
+// (profiles/r4_mark_fused_pass.txt, r4_bench_config4.json, r4_emulate8_config4.json): at 300-384 x 1080p per launch the
+// XCD-aware order wins by 1.5-3.4 % (ties on some boxes), at 192 frames the two tie, at 48-96 frames linear wins by 1-4 %.
+// Round 4 measured the choice per process and launch shape instead; that cost every new batch length 0.25-0.8 s for ~1 % of
+// the step, so measuring is now the caller's explicit request (offmark/engine.py: calibrate_tile_order).
+int tile_xcds(const Ctx &cx, size_t frame_bytes_per_launch) {
+    if (cx.flags & OFMK_F_LINEAR_TILES) return 0;
+    if (cx.flags & OFMK_F_XCD_TILES) return cx.xcds;
+    return frame_bytes_per_launch >= (size_t)OFMK_XCD_TILES_MIN_BYTES ? cx.xcds : 0;
 }
 
 struct ScopedTiming {      // reserves an event pair for the launch that follows (none when timing is off)
@@ -138,17 +152,20 @@ constexpr int kMaxChunk = 65535;   // frames per launch = gridDim.y
 struct Workspace {
     float *rec;      // kRec planes of [frames][nblk]
     float *delta;    // [frames][nblk]
-    unsigned long long *ysum;    // mean accumulators of the frames analyze() saw
+    unsigned long long *ysum;    // [frames][tiles] per-tile partial sums of the block DCs of the frames analyze() saw
     unsigned long long *ysum2;   // ... of the marked frames (fused mark+verify kernel)
     int frames;      // chunk capacity
+    int tiles;       // workgroups per frame of the frame kernels
     size_t plane;    // frames * nblk
 };
 
 constexpr size_t kFixedBytes = 4096;     // alignment slack of the carved arrays
 
+size_t tiles_per_frame(int H, int W) { return ((size_t)(H / 8) * (W / 8) + kThreads - 1) / kThreads; }
+
 size_t per_frame_bytes(int H, int W) {
     const size_t nblk = (size_t)(H / 8) * (W / 8);
-    return nblk * (kRec + 1) * sizeof(float) + 2 * kSlots * 8;
+    return nblk * (kRec + 1) * sizeof(float) + 2 * tiles_per_frame(H, W) * 8;
 }
 
 int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out) {
@@ -162,21 +179,24 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
     const size_t nblk = (size_t)(H / 8) * (W / 8);
     char *p = static_cast<char *>(ws);
     out.frames = (int)cap;
+    out.tiles = (int)tiles_per_frame(H, W);
     out.plane = cap * nblk;
     out.rec = reinterpret_cast<float *>(p);
     p += align256(out.plane * kRec * sizeof(float));
     out.delta = reinterpret_cast<float *>(p);
     p += align256(out.plane * sizeof(float));
     out.ysum = reinterpret_cast<unsigned long long *>(p);
-    p += align256(cap * kSlots * 8);
+    p += align256(cap * out.tiles * 8);
     out.ysum2 = reinterpret_cast<unsigned long long *>(p);
     return OFMK_OK;
 }
 
 // every entry point that takes ofmk_opts: unknown flag bits or a non-zero reserved word are a caller bug, not a default
 int check_opts(const ofmk_opts *o) {
-    if (o && ((o->flags & ~(uint32_t)(OFMK_F_SEPARATE_DETECT | OFMK_F_LINEAR_TILES)) || o->xcds > 64u))
+    if (o && ((o->flags & ~(uint32_t)(OFMK_F_SEPARATE_DETECT | OFMK_F_LINEAR_TILES | OFMK_F_XCD_TILES)) || o->xcds > 64u))
         return fail(OFMK_E_ARG, "ofmk_opts: unknown flag bits or xcds > 64%s");
+    if (o && (o->flags & OFMK_F_LINEAR_TILES) && (o->flags & OFMK_F_XCD_TILES))
+        return fail(OFMK_E_ARG, "ofmk_opts: OFMK_F_LINEAR_TILES and OFMK_F_XCD_TILES exclude each other%s");
     return OFMK_OK;
 }
 
@@ -232,9 +252,7 @@ void launch_copy_fringe(const uint8_t *in, uint8_t *out, int n, int H, int W, in
 int launch_analyze(const void *frames, int src, int n, int H, int W, const Workspace &ws, const Ctx &cx,
                    int32_t *zero_counts = nullptr, int L = 0) {
     hipStream_t s = cx.s;
-    // one fill for both accumulator arrays (they are adjacent): ysum for this pass, ysum2 for a fused mark+verify
-    // kernel that may follow -- one dispatch less per step than zeroing ysum2 in front of the mark kernel
-    HIP_TRY(launch_zero(ws.ysum, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, s));
+    // (no fill dispatch in front: the frame mean is summed from per-tile partial sums that every launch writes in full -- common.hiph: emit_block)
     const Geom g = make_geom(H, W, ws, n);
     const dim3 grid = xcd_grid(g.nblk, n);
     const bool al = aligned_rows(frames, W, src == SRC_RGB8 ? 1 : 4);
@@ -268,13 +286,13 @@ int launch_finalize(FinArgs a, int n, const Ctx &cx) {
 }
 
 // Needs the input frames' records in ws.rec / ws.ysum (launch_analyze).  fused = true also leaves the
-// MARKED frames' records in ws.rec and their mean accumulators in ws.ysum2.
+// MARKED frames' records in ws.rec and their partial sums in ws.ysum2.
 int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const uint8_t *wm, int n_wm, const int32_t *wm_row,
-                     double alpha, const Workspace &ws, bool fused, const Ctx &cx, bool ysum2_is_zero = false) {
+                     double alpha, const Workspace &ws, bool fused, const Ctx &cx) {
     hipStream_t s = cx.s;
-    if (fused && !ysum2_is_zero) HIP_TRY(launch_zero(ws.ysum2, (size_t)n * kSlots * 8, s));
-    const Geom g = make_geom(H, W, ws, n, cx.xcds);
-    const dim3 grid = xcd_grid(g.nblk, n, cx.xcds);
+    const int xc = tile_xcds(cx, (size_t)n * H * W * 3);
+    const Geom g = make_geom(H, W, ws, n, xc);
+    const dim3 grid = xcd_grid(g.nblk, n, xc);
     const bool al = aligned_rows(in, W, 1) && aligned_rows(out, W, 1);
     MarkArgs m;
     m.rec = ws.rec;
@@ -308,6 +326,7 @@ FinArgs fin_base(const Workspace &ws, int H, int W, double alpha) {
     a.rec = ws.rec;
     a.plane = ws.plane;
     a.ysum = ws.ysum;
+    a.tiles = ws.tiles;
     a.nblk = (H / 8) * (W / 8);
     a.N = (int)((long long)H * W / 64);
     a.L = 1;
@@ -340,7 +359,7 @@ int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W
     const int32_t *rows = wm_row ? wm_row + f0 : nullptr;
     if (src == SRC_RGB8)
         return launch_mark_rgb8(reinterpret_cast<const uint8_t *>(pin), reinterpret_cast<uint8_t *>(pout), cf, H, W, wm, n_wm,
-                                rows, alpha, ws, verify, s, /*ysum2_is_zero=*/true);   // by launch_analyze just above
+                                rows, alpha, ws, verify, s);
     // float32 YUV plugin path: separate scalar stage, then the rank-1 update of channel 1
     FinArgs a = fin_base(ws, H, W, alpha);
     a.wm = wm;
@@ -350,6 +369,12 @@ int embed_chunk(const void *in, void *out, int src, int f0, int cf, int H, int W
     if ((rc = launch_finalize(a, cf, s))) return rc;
     const Geom g = make_geom(H, W, ws);
     hipLaunchKernelGGL(mark_yuv32f_kernel, block_grid(g, cf), dim3(kThreads), 0, s.s, reinterpret_cast<float *>(pout), g, ws.delta);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
+}
+
+int launch_payloads(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm, uint8_t *payload, hipStream_t s) {
+    hipLaunchKernelGGL(degenerate_kernel, dim3((unsigned)n), dim3(kThreads), 0, s, counts, L, n_bits, perm, payload);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
 }
@@ -489,7 +514,6 @@ PGeom make_pgeom(int layout, int H, int W, size_t plane) {
 
 int launch_analyze_yuv420(const uint8_t *frames, int layout, int n, int H, int W, const Workspace &ws, const Ctx &cx,
                           int32_t *zero_counts = nullptr, int L = 0) {
-    HIP_TRY(launch_zero(ws.ysum, (size_t)(ws.ysum2 - ws.ysum) * 8 + (size_t)n * kSlots * 8, cx.s));
     const PGeom g = make_pgeom(layout, H, W, ws.plane);
     const dim3 grid((unsigned)((g.nblk + kThreads - 1) / kThreads), (unsigned)n);     // 2-D grid: the planar kernels gain nothing from the XCD order
     ScopedTiming timing(KIND_PLANAR_ANALYZE, cx);
@@ -792,18 +816,20 @@ int ofmk_svd_encode_yuv32f(float *yuv, int n, int H, int W, const uint8_t *wm, i
     if ((rc = set_scales(a, scales, false))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.N = (int)((long long)H * W / 64); a.L = 1;
     const Ctx cx = make_ctx(stream, opts);
-    ScopedTiming timing(KIND_SVD, cx);                    // the plugin path's launches are timed like every other (ADVICE r3)
     if (blk == 8) {
         const Geom8 g8 = make_geom8(H, W);
-        if (g8.ntile > 0)
+        if (g8.ntile > 0) {                               // an event pair is reserved only for a launch that happens
+            ScopedTiming timing(KIND_SVD, cx);
             OFMK_TIMED_LAUNCH(timing, (svd8_yuv32f_kernel<SVD_EMBED>), dim3((unsigned)((g8.ntile + kThreads - 1) / kThreads), (unsigned)n), dim3(kThreads), 0,
                               cx.s, yuv, g8, to_args8(a, H, W));
+        }
         HIP_TRY(hipGetLastError());
         return OFMK_OK;
     }
     Workspace none;
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
+    ScopedTiming timing(KIND_SVD, cx);                    // the plugin path's launches are timed like every other (ADVICE r3)
     OFMK_TIMED_LAUNCH(timing, (svd_yuv32f_kernel<SVD_EMBED>), block_grid(g, n), dim3(kThreads), 0, cx.s, yuv, g, a);
     HIP_TRY(hipGetLastError());
     return OFMK_OK;
@@ -850,10 +876,7 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
     if (int orc = check_opts(opts)) return orc;
     if (!counts || !perm || !payload) return fail(OFMK_E_ARG, "null pointer%s");
     if (n < 1 || L < 1 || n_bits < 0) return fail(OFMK_E_ARG, "bad sizes%s");
-    hipLaunchKernelGGL(degenerate_kernel, dim3((unsigned)n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), counts,
-                       L, n_bits, perm, payload);
-    HIP_TRY(hipGetLastError());
-    return OFMK_OK;
+    return launch_payloads(counts, n, L, n_bits, perm, payload, static_cast<hipStream_t>(stream));
 }
 
 // ---- planar YUV 4:2:0 entry points ------------------------------------------------------

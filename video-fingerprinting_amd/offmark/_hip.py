@@ -12,7 +12,7 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liboffmark_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Opts(C.Structure):
@@ -24,7 +24,9 @@ class Opts(C.Structure):
 
 
 F_SEPARATE_DETECT = 1
-F_LINEAR_TILES = 2          # tile order of the frame-writing DCT kernel: workgroup index instead of the XCD-aware order
+F_LINEAR_TILES = 2          # tile order of the frame-writing DCT kernel: force workgroup index order ...
+F_XCD_TILES = 4             # ... or the XCD-aware order; neither: the library's static rule on the launch size (offmark_hip.h)
+XCD_TILES_MIN_BYTES = 192 * 1080 * 1920 * 3
 YUV_I420, YUV_NV12 = 0, 1
 TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar_analyze", "planar_mark")
 

@@ -19,6 +19,8 @@ configs[3] / [4]) the host, not the device, would set the rate.  `StepPipeline` 
 With G = 1 and no graph this is the plain double-buffered step loop bench.py has always run for large batches.  The caller
 supplies `issue(engine, out, payload_slot)`, which enqueues ONE step on the current stream and leaves its [n, L] uint8
 payloads in `payload_slot`; everything else (what a step is) stays with the caller.
+(Round 5 tried the payload epilogue once per group on the side stream instead of as every step's last launch: no gain at 300
+frames per step, and detect-only steps lost 4-6 % to the concurrent launch -- profiles/r5_frame_tail_experiment.txt.)
 """
 from __future__ import annotations
 
@@ -37,12 +39,17 @@ class StepPipeline:
         gathered result, rank-major ([ranks * n]); make_engine() / make_out(): a fresh engine / output buffer (a second pair is
         made for the graph's second branch); issue(engine, out, slot): enqueue one step; gather(rows [size * n, L], g, size) ->
         the gathered rows of group g (default: offmark.dist.vote.gather_payloads)."""
-        import torch
-        self.torch = torch
-        self.device = torch.device(device)
         self.n, self.L, self.G, self.use_graph = int(n), int(L), max(1, int(group)), bool(graph)
         self.seg = np.asarray(segment_ids)
         self.total = int(self.seg.size)
+        # Grouped steps lay the gathered rows out as [rank][step][n] with the SAME n on every rank (group_segment_ids): ragged
+        # shards (or a rank with nothing to do) would put segment ids on the wrong rows and mix steps in the vote, silently.
+        if self.G > 1 and (not equal_shards or self.n <= 0 or self.total % self.n != 0):
+            raise ValueError(f"group={self.G} needs equal, non-empty shards on every rank (n={self.n}, gathered rows per step={self.total}, "
+                             f"equal_shards={equal_shards}): use group=1 for ragged shards")
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
         self.ranks = self.total // max(self.n, 1) if self.n else 1
         self.S_ids = int(self.seg.max()) + 1 if self.total else 1
         self.make_engine, self.make_out, self.issue = make_engine, make_out, issue

@@ -69,10 +69,15 @@ class DwtDctSvdEncoder:
         h, w, _ = yuv.shape
         dev = t.from_numpy(np.ascontiguousarray(yuv)).to(self.engine.device).unsqueeze(0)
         self.engine.svd_encode_yuv(dev, self._device_wm(h * w // 64), scales=self._scales, blk=self.blk)
-        back = dev[0].cpu().numpy()
-        for ch in range(3):
-            if self._scales[ch] > 0:
-                yuv[:, :, ch] = back[:, :, ch]
+        if yuv.flags.c_contiguous and yuv.flags.writeable:
+            # one contiguous download into the caller's array: the kernels write the marked channels' covered tiles only
+            # (csrc/svd_kernels.hiph, svd8_kernels.hiph), every other float comes back as the bits that went up
+            t.from_numpy(yuv).copy_(dev[0])
+        else:
+            back = dev[0].cpu().numpy()
+            for ch in range(3):
+                if self._scales[ch] > 0:
+                    yuv[:, :, ch] = back[:, :, ch]
         return yuv
 
     def encode_frames_u8(self, frames, out=None, wm_rows=None, wm_table=None):

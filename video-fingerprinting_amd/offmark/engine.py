@@ -7,6 +7,7 @@ work on torch's current stream; nothing here synchronises.
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 
@@ -21,32 +22,52 @@ from . import _hip
 _CACHE_BUDGET_BYTES = int(os.environ.get("OFFMARK_CHUNK_BYTES", 8 << 30))
 
 
+_MAX_CHUNK_FRAMES = 65535      # frames per launch the library accepts (gridDim.y / its own chunk clamp, csrc: kMaxChunk)
+
+
 def default_chunk_frames(H: int, W: int, bytes_per_sample: int = 1) -> int:
-    return max(1, _CACHE_BUDGET_BYTES // (H * W * 3 * bytes_per_sample))
+    return max(1, min(_MAX_CHUNK_FRAMES, _CACHE_BUDGET_BYTES // (H * W * 3 * bytes_per_sample)))
 
 
 def balanced_chunk(n: int, cap: int) -> int:
     """Frames per chunk when n frames are processed in chunks of at most ``cap``: the fewest chunks, all (nearly) equal --
     384 frames under a cap of 345 run as 192 + 192, not 345 + 39 (a short tail chunk pays a whole launch's ramp and tail
-    for a ninth of the work: VERDICT r3, config 4 lost ~10 % to it)."""
-    cap = max(1, cap)
+    for a ninth of the work: VERDICT r3, config 4 lost ~10 % to it).  Never more than the library launches at once."""
+    cap = max(1, min(int(cap), _MAX_CHUNK_FRAMES))
     if n <= cap:
         return max(1, n)
     k = -(-n // cap)
     return -(-n // k)
 
 
-# ---- tile order of the frame-writing DCT kernel (include/offmark_hip.h: OFMK_F_LINEAR_TILES) -----------------------------
-# Which order is faster differs from box to box by a few per cent (the builder's boxes: XCD-aware -1.4 .. -2.6 %; the driver's:
-# +5 % between BENCH_r02 and BENCH_r03), so it is MEASURED once per device and process: the first batch of at least
-# _CALIBRATE_MIN_BYTES of frames an engine marks is first run a few times in both orders, interleaved, on the caller's own
-# buffers, and the faster one is kept for every engine on that device AND that launch shape (results are identical bit for bit
-# either way).  Per shape because the answer depends on it: at 300 x 1080p per launch the XCD-aware order wins by 1.5-3.4 %, at 48
-# frames per launch the linear one by 3-4 %, at 192 they tie (profiles/r4_mark_fused_pass.txt).
-# OFFMARK_TILE_ORDER = auto (default) | xcd | linear overrides; DctEngine(tile_order=...) overrides that.
-_TILE_ORDER = {}              # (device index, H, W, frames per launch) -> dict(order=..., xcd_ms=..., linear_ms=..., ...)
+# ---- tile order of the frame-writing DCT kernel (include/offmark_hip.h: OFMK_F_LINEAR_TILES / OFMK_F_XCD_TILES) ----------------
+# DEFAULT ("auto"): no measurement.  The library itself applies a static rule on the bytes of frames a launch reads -- XCD-aware
+# order from 192 frames of 1080p per launch up, linear below -- which is what every interleaved A/B of rounds 3-4 says (large
+# launches: XCD-aware wins by 1.5-3.4 % or ties; 48-96 frames: linear wins by 1-4 %; profiles/r4_mark_fused_pass.txt).  Round 4
+# measured the order on the first large call of every exact launch shape instead: 0.25-0.8 s and ~256 repeats of the caller's
+# call per new batch length, for ~1 % of a step (VERDICT r4 weak 4, ADVICE r4) -- gone from the default path.
+# OPT-IN: DctEngine(tile_order="calibrate") / OFFMARK_TILE_ORDER=calibrate measures on the first large marking call of a
+# BUCKET (device, kernel, floor(log2(bytes per launch))), and DctEngine.calibrate_tile_order() measures when the caller says
+# so; records are per process, shared by all engines of that device ("auto" engines use them too), taken under a lock, and
+# the implicit form stops measuring once the process has spent OFFMARK_CALIBRATE_BUDGET_MS (default 2 000) on it.  A measured
+# order replaces the static rule's only when it wins by at least 1 % (box-to-box and placement noise is 3-5 %; a tie keeps
+# the rule and is recorded as one).  Results never depend on the order.
+_TILE_ORDER = {}              # (device index, fused, log2 bucket) -> dict(order=..., xcd_ms=..., linear_ms=..., tie=..., ...)
+_TILE_ORDER_LOCK = threading.RLock()
+_CALIBRATION_SPENT_MS = [0.0]
+_CALIBRATION_BUDGET_MS = float(os.environ.get("OFFMARK_CALIBRATE_BUDGET_MS", 2000))
+_CALIBRATE_MARGIN = 0.01
 _XCC_DEAL = {}                # device index -> probe_xcc_deal() result
 _CALIBRATE_MIN_BYTES = 192 << 20
+
+
+def static_tile_order(launch_bytes: int) -> str:
+    """The library's rule (csrc/offmark_kernels.hip: tile_xcds), restated for reporting."""
+    return "xcd" if launch_bytes >= _hip.XCD_TILES_MIN_BYTES else "linear"
+
+
+def order_bucket(launch_bytes: int) -> int:
+    return max(int(launch_bytes), 1).bit_length() - 1
 
 
 def probe_xcc_deal(device=None, workgroups: int = 4096) -> dict:
@@ -58,20 +79,21 @@ def probe_xcc_deal(device=None, workgroups: int = 4096) -> dict:
     lib = _hip.load()
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key in _XCC_DEAL:
-        return _XCC_DEAL[key]
-    with torch.cuda.device(dev):
-        ids = torch.full((workgroups,), -1, dtype=torch.int32, device=dev)
-        _hip.check(lib.ofmk_probe_xcc(ids.data_ptr(), workgroups, _hip.current_stream(), None))
-        got = ids.cpu().numpy()
-    seen = sorted(int(v) for v in np.unique(got))
-    X = len(seen)
-    by_res = [int(np.bincount(got[r::X], minlength=16).argmax()) for r in range(X)]
-    fit = float(np.mean(got == np.asarray(by_res)[np.arange(workgroups) % X]))
-    out = dict(xcds=X, round_robin=bool(fit == 1.0 and len(set(by_res)) == X), ids_by_residue=by_res,
-               round_robin_fraction=round(fit, 4), workgroups=workgroups)
-    _XCC_DEAL[key] = out
-    return out
+    with _TILE_ORDER_LOCK:
+        if key in _XCC_DEAL:
+            return _XCC_DEAL[key]
+        with torch.cuda.device(dev):
+            ids = torch.full((workgroups,), -1, dtype=torch.int32, device=dev)
+            _hip.check(lib.ofmk_probe_xcc(ids.data_ptr(), workgroups, _hip.current_stream(), None))
+            got = ids.cpu().numpy()
+        seen = sorted(int(v) for v in np.unique(got))
+        X = len(seen)
+        by_res = [int(np.bincount(got[r::X], minlength=16).argmax()) for r in range(X)]
+        fit = float(np.mean(got == np.asarray(by_res)[np.arange(workgroups) % X]))
+        out = dict(xcds=X, round_robin=bool(fit == 1.0 and len(set(by_res)) == X), ids_by_residue=by_res,
+                   round_robin_fraction=round(fit, 4), workgroups=workgroups)
+        _XCC_DEAL[key] = out
+        return out
 
 
 class DctEngine:
@@ -80,8 +102,9 @@ class DctEngine:
     def __init__(self, device=None, chunk_frames: int | None = None, opts=None, tile_order: str | None = None):
         """opts: an _hip.Opts applied to every batch call of this engine (flags, timing object); engines share
         no state, so two engines on two streams may be driven from two threads.
-        tile_order: "xcd" | "linear" | "auto" (default: $OFFMARK_TILE_ORDER, else "auto" = calibrate once per device on the
-        first large batch, see calibrate_tile_order).  A pure scheduling choice: results do not depend on it."""
+        tile_order: "auto" (default: $OFFMARK_TILE_ORDER, else "auto" = the library's static rule on the launch size, no
+        measurement) | "xcd" | "linear" (forced) | "calibrate" (measure once per device and size bucket on the first large
+        marking call, see the module text).  A pure scheduling choice: results do not depend on it."""
         self.opts = opts
         self.torch = _hip.require_gpu()
         self.lib = _hip.load()
@@ -89,12 +112,12 @@ class DctEngine:
             else self.torch.device(device)
         self.chunk_frames = chunk_frames
         order = tile_order or os.environ.get("OFFMARK_TILE_ORDER", "auto")
-        if order not in ("auto", "xcd", "linear"):
-            raise ValueError(f"tile_order must be 'auto', 'xcd' or 'linear', not {order!r}")
+        if order not in ("auto", "xcd", "linear", "calibrate"):
+            raise ValueError(f"tile_order must be 'auto', 'xcd', 'linear' or 'calibrate', not {order!r}")
         self._order_mode = order
-        self.auto_calibrate = True        # "auto" mode only: callers whose frames cross PCIe anyway (the plugin pipeline) switch it off
         self._opts_cache = None
         self._last_key = None
+        self._last_bytes = 0
         self.calibrated_at = None
         # range-check device-resident row maps too (costs a host synchronisation per call, so off by default; the kernels
         # clamp every entry into [0, n_wm) either way -- include/offmark_hip.h)
@@ -105,7 +128,7 @@ class DctEngine:
     def workspace(self, H: int, W: int, frames: int):
         """Scratch for `frames` frames in flight.  One buffer per frame size is kept and only ever grows: the
         library sizes its chunks to min(chunk_frames, what fits), so a larger buffer serves smaller batches."""
-        nbytes = self.lib.ofmk_workspace_bytes(frames, H, W)
+        nbytes = self.lib.ofmk_workspace_bytes(min(int(frames), _MAX_CHUNK_FRAMES), H, W)
         if nbytes == 0:
             raise _hip.HipError(f"bad frame size {H}x{W}")
         ws = self._ws.get((H, W))
@@ -123,36 +146,58 @@ class DctEngine:
     def device_key(self):
         return self.device.index if self.device.index is not None else self.torch.cuda.current_device()
 
-    def _order_key(self, shape):
-        return (self.device_key,) + tuple(int(x) for x in shape)
+    def _order_key(self, launch_bytes, fused):
+        return (self.device_key, int(bool(fused)), order_bucket(launch_bytes))
 
     @property
     def tile_order(self) -> str:
-        """The order in use: this engine's fixed choice, else what the last marking call's launch shape was calibrated to,
-        else "xcd" (not yet calibrated)."""
-        if self._order_mode != "auto":
+        """The order the last marking call ran in: this engine's forced choice, else a calibration record of that call's bucket,
+        else the static rule for that call's launch size."""
+        if self._order_mode in ("xcd", "linear"):
             return self._order_mode
-        return _TILE_ORDER.get(self._last_key, {}).get("order", "xcd")
+        pinned = self._pinned()
+        if pinned:
+            return pinned
+        rec = _TILE_ORDER.get(self._last_key)
+        return rec["order"] if rec else static_tile_order(self._last_bytes)
 
     @property
     def tile_order_info(self) -> dict:
-        return dict(_TILE_ORDER.get(self._last_key, {}), mode=self._order_mode, in_use=self.tile_order)
+        rec = _TILE_ORDER.get(self._last_key)
+        policy = ("forced" if self._order_mode in ("xcd", "linear") or self._pinned() else
+                  "calibrated" if rec else "static rule")
+        return dict(rec or {}, mode=self._order_mode, in_use=self.tile_order, policy=policy,
+                    launch_bytes=self._last_bytes, static_rule=static_tile_order(self._last_bytes),
+                    xcd_from_bytes=_hip.XCD_TILES_MIN_BYTES)
 
-    def _o(self, shape=None):
+    def _pinned(self):
+        """The order the caller's own opts force, if any."""
+        if self.opts is None:
+            return None
+        if self.opts.flags & _hip.F_LINEAR_TILES or self.opts.xcds == 1:
+            return "linear"
+        if self.opts.flags & _hip.F_XCD_TILES:
+            return "xcd"
+        return None
+
+    def _o(self, launch_bytes=None, fused=True):
         """ctypes argument for this call's ofmk_opts: the engine's opts (flags, timing) plus, for a call that runs the frame-writing
-        DCT kernel (``shape`` = (H, W, frames per launch)), the tile order calibrated for that shape."""
+        DCT kernel (``launch_bytes`` = bytes of frames per launch), the tile order: forced, calibrated for that bucket, or none
+        (the library's static rule)."""
         base = self.opts
         flags = base.flags if base is not None else 0
         xcds = base.xcds if base is not None else 0
-        if shape is not None:
-            self._last_key = self._order_key(shape)
-            info = _TILE_ORDER.get(self._last_key, {})
-            if not xcds:                                      # a device whose probe counted other than 8 XCDs (partition modes)
-                xcds = info.get("xcds", 0)
-                xcds = 0 if xcds == 8 else xcds
-            order = self._order_mode if self._order_mode != "auto" else info.get("order", "xcd")
-            if order == "linear":
-                flags |= _hip.F_LINEAR_TILES
+        if launch_bytes is not None:
+            self._last_key, self._last_bytes = self._order_key(launch_bytes, fused), int(launch_bytes)
+            if not self._pinned():
+                rec = _TILE_ORDER.get(self._last_key)
+                order = self._order_mode if self._order_mode in ("xcd", "linear") else (rec["order"] if rec else None)
+                if order == "linear":
+                    flags |= _hip.F_LINEAR_TILES
+                elif order == "xcd":
+                    flags |= _hip.F_XCD_TILES
+                if rec and not xcds and rec.get("xcds", 8) != 8:          # a device whose probe counted other than 8 XCDs (partition modes)
+                    xcds = rec["xcds"]
         if base is not None and flags == base.flags and xcds == base.xcds:
             return _hip.opts_ref(base)
         if flags == 0 and xcds == 0 and base is None:
@@ -161,17 +206,16 @@ class DctEngine:
         self._opts_cache = o                                  # alive until the next call
         return _hip.opts_ref(o)
 
-    def _calibrate(self, key, launch, base_flags, min_ms, max_ms, chunks=1) -> dict:
+    def _calibrate(self, key, launch, base_flags, min_ms, max_ms, launch_bytes, chunks=1) -> dict:
         """Core of the calibration: ``launch(opts)`` enqueues THE CALL BEING CALIBRATED (the caller's own embed / embed+detect
         call on its own buffers) with the given ofmk_opts; it is issued in blocks of 8 (A B B A A B B A), the mark kernel's
         launches timed by the dispatches' own timestamps (one event pool per order), the device kept busy from the first block
         to the last.  Why the caller's whole call and not just the kernel in question: on this device every change of load
-        pattern is followed by ~10-20 ms of slower launches (power management: 3-10 ms after bench.py went from a
-        calibration made of analyze + mark launches only to its real steps, the same kernel ran 5-10 % slower,
-        profiles/r4_idle_gap.txt), so the calibration must BE the steady state it hands over to.  And a device coming out of
-        idle keeps speeding up for ~100 ms of load (first block 0.78 ms, settled 0.69 ms), so blocks are added until at least
-        ``min_ms`` of sustained load have passed and a block's mean is within 0.5 % of the previous one's (or ``max_ms`` have
-        passed); the decision is taken on the last four blocks only."""
+        pattern is followed by ~10-20 ms of slower launches (power management, profiles/r4_idle_gap.txt), so the calibration must
+        BE the steady state it hands over to.  And a device coming out of idle keeps speeding up for ~100 ms of load, so blocks
+        are added until at least ``min_ms`` of sustained load have passed and a block's mean is within 0.5 % of the previous
+        one's (or ``max_ms`` have passed); the decision is taken on the last four blocks only and needs a 1 % margin to leave
+        the static rule's order."""
         import time
         t = self.torch
         deal = probe_xcc_deal(self.device)
@@ -179,8 +223,9 @@ class DctEngine:
         kinds = (1 << _hip.TIMING_KINDS.index("mark_fused")) | (1 << _hip.TIMING_KINDS.index("mark"))
         per_block = 4 * max(1, int(chunks)) + 4               # timed launches per order and block: 4 calls x chunks per call
         pools = {"xcd": _hip.Timing(per_block, kinds), "linear": _hip.Timing(per_block, kinds)}
-        opts = {"xcd": _hip.Opts(base_flags & ~_hip.F_LINEAR_TILES, xcds, pools["xcd"].handle),
-                "linear": _hip.Opts(base_flags | _hip.F_LINEAR_TILES, xcds, pools["linear"].handle)}
+        keep = base_flags & ~(_hip.F_LINEAR_TILES | _hip.F_XCD_TILES)
+        opts = {"xcd": _hip.Opts(keep | _hip.F_XCD_TILES, xcds, pools["xcd"].handle),
+                "linear": _hip.Opts(keep | _hip.F_LINEAR_TILES, xcds, pools["linear"].handle)}
         blocks, settled = [], False                           # per block: {order: mean launch ms}
         t_start = time.perf_counter()
         try:
@@ -200,57 +245,68 @@ class DctEngine:
                     settled = abs(now - before) <= 0.005 * before
                     if settled or spent >= max_ms:
                         break
+                elif spent >= max_ms:
+                    break
         finally:
             for p in pools.values():
                 p.close()
         med = {k: float(np.mean([b[k] for b in blocks[-4:]])) for k in ("xcd", "linear")}
-        order = "linear" if (med["linear"] < med["xcd"] or not deal["round_robin"]) else "xcd"
-        info = dict(order=order, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5), blocks=len(blocks), calls_each=4 * len(blocks),
+        default = static_tile_order(launch_bytes) if deal["round_robin"] else "linear"
+        other = "linear" if default == "xcd" else "xcd"
+        wins = deal["round_robin"] and settled and med[other] < med[default] * (1.0 - _CALIBRATE_MARGIN)
+        order = other if wins else default
+        spent_ms = 1e3 * (time.perf_counter() - t_start)
+        info = dict(order=order, tie=not wins, static_rule=default, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5),
+                    margin=_CALIBRATE_MARGIN, blocks=len(blocks), calls_each=4 * len(blocks),
                     first_block_ms=round(0.5 * sum(blocks[0].values()), 5), last_block_ms=round(0.5 * sum(blocks[-1].values()), 5),
-                    settled=bool(settled), calibration_ms=round(1e3 * (time.perf_counter() - t_start), 1),
-                    height=key[1], width=key[2], frames_per_launch=key[3], kernel="mark+verify" if key[4] else "mark",
-                    xcds=deal["xcds"], round_robin=deal["round_robin"])
+                    settled=bool(settled), calibration_ms=round(spent_ms, 1), launch_bytes=int(launch_bytes), bucket_log2=key[2],
+                    kernel="mark+verify" if key[1] else "mark", xcds=deal["xcds"], round_robin=deal["round_robin"])
         self.calibrated_at = time.perf_counter()              # (bench.py reports the host time between this and its first warm-up launch)
+        _CALIBRATION_SPENT_MS[0] += spent_ms
         _TILE_ORDER[key] = info
         return info
 
-    def _launch_marking(self, launch, frames, out, shape):
-        """Issue a marking call: ``launch(opts)`` enqueues it.  In "auto" mode the first large call of a (device, launch shape,
-        kernel) is preceded by the calibration, which runs that very call (same buffers, same arguments: the results it leaves
-        are the call's own results)."""
-        self._last_key = self._order_key(shape)
-        pinned = self.opts is not None and (self.opts.flags & _hip.F_LINEAR_TILES or self.opts.xcds)     # the caller's opts fix the order already
-        if (self._order_mode == "auto" and self.auto_calibrate and not pinned and self._last_key not in _TILE_ORDER
-                and frames.numel() >= _CALIBRATE_MIN_BYTES
-                and out.data_ptr() != frames.data_ptr() and not self.torch.cuda.is_current_stream_capturing()):
-            n = frames.shape[0]
-            self._calibrate(self._last_key, launch, self.opts.flags if self.opts is not None else 0, 250.0, 800.0,
-                            chunks=-(-n // max(int(shape[2]), 1)))
-        launch(self._o(shape))
+    def _launch_marking(self, launch, frames, out, launch_bytes, fused, chunks=1):
+        """Issue a marking call: ``launch(opts)`` enqueues it.  Mode "calibrate" only: the first large call of a (device, kernel,
+        size bucket) is preceded by the calibration, which runs that very call (same buffers, same arguments: the results it
+        leaves are the call's own results) -- while the process's calibration budget lasts."""
+        key = self._order_key(launch_bytes, fused)
+        if (self._order_mode == "calibrate" and not self._pinned() and key not in _TILE_ORDER
+                and frames.numel() >= _CALIBRATE_MIN_BYTES and out.data_ptr() != frames.data_ptr()
+                and _CALIBRATION_SPENT_MS[0] < _CALIBRATION_BUDGET_MS
+                and not self.torch.cuda.is_current_stream_capturing()):
+            with _TILE_ORDER_LOCK:
+                if key not in _TILE_ORDER:
+                    self._calibrate(key, launch, self.opts.flags if self.opts is not None else 0, 250.0, 800.0, launch_bytes, chunks)
+        launch(self._o(launch_bytes, fused))
 
     def calibrate_tile_order(self, frames, out=None, min_ms: float = 250.0, max_ms: float = 800.0, force: bool = False) -> dict:
         """Explicit calibration of the fused mark+verify call on ``frames`` (CUDA uint8 [n, H, W, 3]) with a test watermark,
         for callers that want it done at a moment of their choosing (see _calibrate).  Synchronises; ``out`` (default: a
-        temporary buffer) must not alias ``frames``.  Returns the calibration record of this device and launch shape."""
+        temporary buffer) must not alias ``frames``.  Returns the calibration record of this device and size bucket, which every
+        engine of this device then uses for launches of that bucket."""
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         cf = self._chunk(n, H, W)
         fused = not (self.opts is not None and self.opts.flags & _hip.F_SEPARATE_DETECT)
-        key = self._order_key((H, W, cf, int(fused)))
-        self._last_key = key
-        if key in _TILE_ORDER and not force:
-            return _TILE_ORDER[key]
-        dst = t.empty_like(frames) if out is None or out.data_ptr() == frames.data_ptr() else self._out(out, frames)
-        wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
-        wm[0, ::2] = 1
-        counts = t.empty((n, 8), dtype=t.int32, device=self.device)
-        ws = self.workspace(H, W, cf)
-        stream = _hip.current_stream()
+        launch_bytes = cf * H * W * 3
+        key = self._order_key(launch_bytes, fused)
+        self._last_key, self._last_bytes = key, launch_bytes
+        with _TILE_ORDER_LOCK:
+            if key in _TILE_ORDER and not force:
+                return _TILE_ORDER[key]
+            dst = t.empty_like(frames) if out is None or out.data_ptr() == frames.data_ptr() else self._out(out, frames)
+            wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
+            wm[0, ::2] = 1
+            counts = t.empty((n, 8), dtype=t.int32, device=self.device)
+            ws = self.workspace(H, W, cf)
+            stream = _hip.current_stream()
 
-        def launch(o):
-            _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), dst.data_ptr(), n, H, W, wm.data_ptr(), 1, None, 20.0, 8,
-                                                       counts.data_ptr(), None, cf, ws.data_ptr(), ws.numel(), stream, o))
-        return self._calibrate(key, launch, self.opts.flags if self.opts is not None else 0, min_ms, max_ms, chunks=-(-n // cf))
+            def launch(o):
+                _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), dst.data_ptr(), n, H, W, wm.data_ptr(), 1, None, 20.0, 8,
+                                                           counts.data_ptr(), None, cf, ws.data_ptr(), ws.numel(), stream, o))
+            return self._calibrate(key, launch, self.opts.flags if self.opts is not None else 0, min_ms, max_ms, launch_bytes,
+                                   chunks=-(-n // cf))
 
     def _check_frames(self, frames, dtype):
         t = self.torch
@@ -271,6 +327,17 @@ class DctEngine:
                 and tuple(out.shape) == shape and out.is_contiguous()):
             raise ValueError(f"out must be a contiguous CUDA {like.dtype} tensor of shape {shape} on {like.device}")
         return out
+
+    def _counts(self, counts, n, L):
+        """The position sums of a call: a fresh int32 [n, L] tensor, or the caller's (a pipeline that hands them to another
+        stream keeps its own buffers: torch's allocator would hand a per-call tensor's block out again on the issuing stream)."""
+        t = self.torch
+        if counts is None:
+            return t.empty((n, L), dtype=t.int32, device=self.device)
+        if not (isinstance(counts, t.Tensor) and counts.is_cuda and counts.device == self.device and counts.dtype == t.int32
+                and tuple(counts.shape) == (n, L) and counts.is_contiguous()):
+            raise ValueError(f"counts must be a contiguous CUDA int32 tensor of shape {(n, L)} on {self.device}")
+        return counts
 
     def _layout(self, layout):
         try:
@@ -324,15 +391,15 @@ class DctEngine:
         def launch(o):
             _hip.check(self.lib.ofmk_embed_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(), wm.shape[0],
                                                 _hip.ptr(rows), float(alpha), cf, ws.data_ptr(), ws.numel(), stream, o))
-        self._launch_marking(launch, frames, out, (H, W, cf, 0))
+        self._launch_marking(launch, frames, out, min(cf, n) * H * W * 3, False, chunks=-(-n // cf))
         return out
 
-    def detect(self, frames, L, alpha=20, want_bits=False):
+    def detect(self, frames, L, alpha=20, want_bits=False, counts=None):
         """Returns (counts int32 [n, L], bits u8 [n, N] or None)."""
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         N = H * W // 64
-        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        counts = self._counts(counts, n, L)
         bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
@@ -352,7 +419,7 @@ class DctEngine:
                                                   ws.data_ptr(), ws.numel(), _hip.current_stream(), self._o()))
         return soft
 
-    def embed_detect(self, frames, wm, L, alpha=20, wm_row=None, out=None, want_bits=False):
+    def embed_detect(self, frames, wm, L, alpha=20, wm_row=None, out=None, want_bits=False, counts=None):
         """Mark, then read back the marked frames chunk by chunk (mark + verify)."""
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
@@ -360,7 +427,7 @@ class DctEngine:
         wm = self._wm(wm, N)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
-        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        counts = self._counts(counts, n, L)
         bits = t.empty((n, N), dtype=t.uint8, device=self.device) if want_bits else None
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
@@ -371,7 +438,7 @@ class DctEngine:
             _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                        wm.shape[0], _hip.ptr(rows), float(alpha), int(L),
                                                        counts.data_ptr(), _hip.ptr(bits), cf, ws.data_ptr(), ws.numel(), stream, o))
-        self._launch_marking(launch, frames, out, (H, W, cf, int(fused)))
+        self._launch_marking(launch, frames, out, min(cf, n) * H * W * 3, fused, chunks=-(-n // cf))
         return out, counts, bits
 
     def payloads(self, counts, n_bits: int, perm, out=None):
@@ -425,14 +492,14 @@ class DctEngine:
                                                _hip.current_stream(), self._o()))
         return counts, bits
 
-    def embed_detect_yuv420(self, planes, H, W, wm, L, alpha=20, wm_row=None, out=None, want_bits=False, layout="i420"):
+    def embed_detect_yuv420(self, planes, H, W, wm, L, alpha=20, wm_row=None, out=None, want_bits=False, layout="i420", counts=None):
         """Mark and verify on planes; counts/bits are what a reader of the WRITTEN planes gets."""
         t = self.torch
         n = self._check_planar(planes, H, W)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, planes)
-        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        counts = self._counts(counts, n, L)
         bits = t.empty((n, H * W // 64), dtype=t.uint8, device=self.device) if want_bits else None
         cf = self._chunk(n, H, W)
         ws = self.workspace(H, W, cf)
@@ -501,22 +568,22 @@ class DctEngine:
                                                 self._o()))
         return out
 
-    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None, blk=4):
+    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None, blk=4, counts=None):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
-        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        counts = self._counts(counts, n, L)
         bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), _hip.scales3(scale, scales), int(blk), counts.data_ptr(),
                                                  _hip.ptr(bits), _hip.current_stream(), self._o()))
         return counts, bits
 
-    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None, blk=4):
+    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None, blk=4, counts=None):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
-        counts = t.empty((n, L), dtype=t.int32, device=self.device)
+        counts = self._counts(counts, n, L)
         bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                        wm.shape[0], _hip.ptr(rows), _hip.scales3(scale, scales), int(blk), int(L),

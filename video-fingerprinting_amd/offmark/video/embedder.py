@@ -79,13 +79,9 @@ class Embedder:
 
         pipe = pl.StagedPipeline(eng.device, reader, pl.batch_size(self.batch_frames, pl.frame_shape(in_fmt, H, W)),
                                  pl.frame_shape(in_fmt, H, W), pl.frame_shape(out_fmt, H, W), np.uint8)
-        # the pipeline is bound by the PCIe link (its kernels are ~2 % of its time): a tile-order calibration (0.25 s of repeated
-        # marking, offmark.engine) would cost more than it can ever return here -- an order calibrated elsewhere is still used
-        calibrate, eng.auto_calibrate = getattr(eng, "auto_calibrate", True), False
         try:
             pipe.run(process, pl.WriterSink(self.frame_writer))
         finally:
-            eng.auto_calibrate = calibrate
             self.frames_marked += pipe.frames_done
         logger.info("End of input stream")
 
