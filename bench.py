@@ -396,8 +396,12 @@ def bind_to_gpu_numa(gpu_of_rank, local_rank):
             info["note"] = "no core of that node in this process's affinity mask"
             return info
         os.sched_setaffinity(0, mine)
-        info.update(bound=True, cpus=f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine)),
-                    n_cpus=len(mine), ranks_on_node=len(peers))
+        runs, start = [], mine[0]                                        # compact cpulist form: 0-63,128-191
+        for a_, b_ in zip(mine, mine[1:] + [None]):
+            if b_ != a_ + 1:
+                runs.append(f"{start}-{a_}" if a_ != start else str(a_))
+                start = b_
+        info.update(bound=True, cpus=",".join(runs), n_cpus=len(mine), ranks_on_node=len(peers))
     except Exception as exc:
         info["error"] = repr(exc)
     return info
@@ -451,6 +455,7 @@ def main():
     # placement first: nothing has touched the GPU yet (no torch import, no HIP call)
     env_world, env_local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     n_local = int(os.environ.get("LOCAL_WORLD_SIZE", env_world))
+    affinity_at_start = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     placement = dict(bound=False, note="--no-bind") if a.no_bind else \
         bind_to_gpu_numa([0] * n_local if a.single_device else list(range(n_local)), env_local)
     import torch
@@ -1187,6 +1192,8 @@ def main():
         dist.destroy_process_group()
     if not a.no_cpu_baseline and a.codec == "dct" and mode == "embed_detect":
         try:
+            if affinity_at_start:                      # the CPU baseline may use every core this process was given, not just the GPU-local ones
+                os.sched_setaffinity(0, affinity_at_start)
             nb = 96 if H * W <= 1920 * 1080 else 24
             wm_cpu = Shuffler(key=0).generate_wm(PAYLOAD, (1, N))
             line["cpu_baseline"] = cpu_baseline(synthetic_frames(nb, H, W, seed=2000, device=dev).cpu().numpy(), wm_cpu, a.alpha, a.cpu_seconds)

@@ -1279,13 +1279,14 @@ def test_bench_rank_failure_ends_the_whole_job(where, flags):
     assert r.returncode != 0 and took < 60, (r.returncode, took, r.stderr[-1500:])
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[-500:]
     assert f"injected failure in rank 1 at {where}" in r.stderr
-    if where == "second_pass":          # the healthy twin of the same command, and the one-GPU run of the same arguments
+    if where == "second_pass":          # the healthy twin, and the one-GPU run of the same arguments, at a size where the work (not the interpreter start-up) sets the time
+        big = ["--backend", "gloo", "--single-device", "--frames", "60", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"]
         t0 = time.perf_counter()
-        ok2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *args], capture_output=True, text=True,
+        ok2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *big], capture_output=True, text=True,
                              timeout=600, env=env, cwd=root)
         t2 = time.perf_counter() - t0
         t0 = time.perf_counter()
-        ok1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *args[3:]], capture_output=True, text=True,
+        ok1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", *big[3:]], capture_output=True, text=True,
                              timeout=600, env=env, cwd=root)
         t1 = time.perf_counter() - t0
         assert ok2.returncode == 0 and ok1.returncode == 0, (ok2.stderr[-1500:], ok1.stderr[-1500:])

@@ -57,5 +57,7 @@ for f in sorted(glob.glob("$O/${TAG}_*.json")):
     if "emulation" in l:
         e = l["emulation"]; print("    emulation:", {k: e[k] for k in ("world", "shard_frames", "steps_per_host_iteration", "hipgraph", "shard_ms_per_step", "full_job_ms_per_step", "predicted_speedup", "predicted_frames_per_s", "host_ms_per_step")})
     if "mark_order" in l:
-        m = l["mark_order"]; print("    mark_order:", {k: m.get(k) for k in ("xcd_ms", "linear_ms", "xcd_step_ms", "linear_step_ms", "shipped", "calibration")})
+        m = l["mark_order"]; print("    mark_order:", {k: m.get(k) for k in ("xcd_ms", "linear_ms", "xcd_step_ms", "linear_step_ms", "shipped", "policy")})
+    for k in ("embed_only", "detect_only"):
+        if k in l and "value" in l[k]: print("    %s:" % k, {q: l[k].get(q) for q in ("value", "ms_per_step", "frac_of_peak", "frac_of_measured_copy", "frac_of_measured_read")})
 PY
