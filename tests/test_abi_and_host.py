@@ -398,3 +398,23 @@ def test_balanced_chunks():
             c = E.balanced_chunk(n, cap)
             k = -(-n // c)
             assert 1 <= c <= max(cap, 1) and k == -(-n // min(cap, n)) and n - (k - 1) * c > c - k      # same chunk count as the cap gives; last chunk within k of the rest
+
+
+def test_chunk_choice_never_exceeds_what_the_library_launches():
+    """with the 8 GiB byte cap tiny frames gave a Python-side chunk above the library's 65 535 frames per launch (gridDim.y,
+    csrc kMaxChunk), so the workspace, the timing pool and the order bucket were computed for a launch shape that never runs.
+    The engine's chunk helpers and the static tile-order rule restated for reporting (include/offmark_hip.h)."""
+    import importlib
+    E = importlib.import_module("offmark.engine")
+    from offmark import _hip
+    assert E.default_chunk_frames(8, 8) == 65535 and E.default_chunk_frames(16, 16) == 65535
+    assert E.balanced_chunk(200000, 10 ** 9) == 50000 and E.balanced_chunk(65535, 10 ** 9) == 65535      # 4 equal chunks under the clamp
+    assert E.default_chunk_frames(1080, 1920) == (8 << 30) // (1080 * 1920 * 3)
+    assert _hip.XCD_TILES_MIN_BYTES == 192 * 1080 * 1920 * 3
+    header = open(os.path.join(ROOT, "include", "offmark_hip.h")).read()
+    assert f"#define OFMK_XCD_TILES_MIN_BYTES {_hip.XCD_TILES_MIN_BYTES}ull" in header
+    assert E.static_tile_order(_hip.XCD_TILES_MIN_BYTES) == "xcd" and E.static_tile_order(_hip.XCD_TILES_MIN_BYTES - 1) == "linear"
+    assert E.order_bucket(48 * 1080 * 1920 * 3) == E.order_bucket(60 * 1080 * 1920 * 3) == 28 and E.order_bucket(40 * 1080 * 1920 * 3) == 27
+    assert (_hip.F_SEPARATE_DETECT, _hip.F_LINEAR_TILES, _hip.F_XCD_TILES) == (1, 2, 4)
+    for name, value in (("OFMK_F_SEPARATE_DETECT", 1), ("OFMK_F_LINEAR_TILES", 2), ("OFMK_F_XCD_TILES", 4)):
+        assert f"#define {name} {value}u" in header
