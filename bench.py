@@ -103,6 +103,8 @@ def parse():
     ap.add_argument("--tile-order", choices=["auto", "xcd", "linear", "calibrate"], default="auto",
                     help="tile order of the fused mark kernel: auto = the library's static rule on the launch size (default, no "
                          "measurement); calibrate = the engine measures once per size bucket at set-up")
+    ap.add_argument("--preheat-ms", type=float, default=250.0,
+                    help="untimed steps of the workload for about this long in set-up, before the W warm-up steps (device out of idle; 0 = none)")
     ap.add_argument("--side-measurements", action="store_true",
                     help="N > 1: also run the side measurements (default there: value and second_pass only)")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the rank to its GPU's NUMA-local cores")
@@ -664,6 +666,28 @@ def main():
                     e.workspace(H, W, e._chunk(self.j.n, H, W))
             super().prepare()
 
+        def preheat(self, ms):
+            """Bring the device from idle to its operating state before the contract's W warm-up steps: untimed steps of the
+            workload itself for about `ms` milliseconds (--preheat-ms, reported as config.preheat_ms; 0 = none).  A device
+            coming out of idle keeps speeding up for ~100 ms of load (profiles/r4_idle_gap.txt: first launches 0.79 ms, settled
+            0.70), and W = 5 warm-up steps are 6 ms of it: without this a short timed region measures the ramp, not the path
+            (20 steps from cold: 260 k frames/s, the same 20 steps straight after: 274 k).  Rounds 1-4 had it implicitly (round 4's
+            tile-order calibration in set-up was 279 ms of load); now it is explicit, bounded and in the line.  Not a workload
+            step: nothing here is timed or counted, and every rank does the same (grouped steps keep their collectives in step)."""
+            if ms <= 0 or not self.j.n:
+                return 0.0
+            t0 = time.perf_counter()
+            chunk_steps = max(self.G, self.G * max(1, int(8 // max(self.G, 1))))          # ~8 steps between host checks, whole groups
+            while 1e3 * (time.perf_counter() - t0) < ms:
+                self.run(chunk_steps)
+                torch.cuda.synchronize()
+                if grouped:          # the ranks agree when to stop: the slowest rank's clock decides (a collective every ~10 ms)
+                    go = torch.tensor([1.0 if 1e3 * (time.perf_counter() - t0) < ms else 0.0], device=dev if a.backend == "nccl" else "cpu")
+                    dist.all_reduce(go, op=dist.ReduceOp.MIN)
+                    if float(go.item()) == 0.0:
+                        break
+            return round(1e3 * (time.perf_counter() - t0), 1)
+
         def fence(self):
             torch.cuda.synchronize()
             if grouped:
@@ -740,6 +764,7 @@ def main():
             p1 = lanes[0].pay[0, :1].reshape(-1, L)
             gather_payloads(p1.cpu() if a.backend == "gloo" else p1, equal_shards=job.equal, force=grouped)
         torch.cuda.synchronize()
+    preheat_ms = runner.preheat(a.preheat_ms)
     runner.set_opts(opts_timed)                             # every dominant-kernel launch of the timed steps carries its own event pair ...
     cal_at = lanes[0].eng.calibrated_at
     setup_gap_ms = round(1e3 * (time.perf_counter() - cal_at), 2) if cal_at else None     # host time from the calibration's last launch to here
@@ -1163,6 +1188,7 @@ def main():
         "config": {"workload": workload + f"{codec_name} {op}+vote (BASELINE.json {what})",
                    "codec": a.codec, "frames_per_gpu": n, "payload_bits": L, "alpha": a.alpha,
                    "chunk_frames": chunk, "chunks_per_step": n_chunks, "steps_per_host_iteration": G, "hipgraph": bool(use_graph),
+                   "preheat_ms": preheat_ms,
                    "tile_order": shipped_order if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "tile_order_policy": shipped_info.get("policy") if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")

@@ -10,9 +10,10 @@ OUT=$PWD/gpurun_out/prof_$TAG
 ROOT=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-extras $*"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --preheat-ms 0 --no-cpu-baseline --no-kernel-events --no-extras $*"
 # the kernel-trace pass runs enough steps for its per-kernel AVERAGE to describe the device at its operating clocks (a 5-step run from idle
-# sits on the clock ramp: round 2's 8-call averages were 6-8 % above the bench line's in-run event averages); counters do not care
+# sits on the clock ramp: round 2's 8-call averages were 6-8 % above the bench line's in-run event averages), bench.py's own pre-heat included
+# (its launches are in the average: the same kernels on the same data); counters do not care and skip the pre-heat
 TRACE="python3 $ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-kernel-events --no-extras $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $TRACE > $OUT/trace.log 2>&1
