@@ -678,14 +678,16 @@ def main():
                 return 0.0
             t0 = time.perf_counter()
             chunk_steps = max(self.G, self.G * max(1, int(8 // max(self.G, 1))))          # ~8 steps between host checks, whole groups
-            while 1e3 * (time.perf_counter() - t0) < ms:
+            while True:
                 self.run(chunk_steps)
                 torch.cuda.synchronize()
-                if grouped:          # the ranks agree when to stop: the slowest rank's clock decides (a collective every ~10 ms)
-                    go = torch.tensor([1.0 if 1e3 * (time.perf_counter() - t0) < ms else 0.0], device=dev if a.backend == "nccl" else "cpu")
-                    dist.all_reduce(go, op=dist.ReduceOp.MIN)
-                    if float(go.item()) == 0.0:
-                        break
+                go = 1e3 * (time.perf_counter() - t0) < ms
+                if grouped:          # every step gathers over the ranks, so the ranks must stop after the SAME chunk: the first rank
+                    flag = torch.tensor([1.0 if go else 0.0], device=dev if a.backend == "nccl" else "cpu")      # whose clock says so decides for all
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    go = float(flag.item()) != 0.0
+                if not go:
+                    break
             return round(1e3 * (time.perf_counter() - t0), 1)
 
         def fence(self):
