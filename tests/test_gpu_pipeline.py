@@ -326,10 +326,9 @@ def test_timing_options_do_not_dangle(eng):
     t3.collect()
     # blk = 8 on a frame with no 16x16 tile launches nothing -- and must not take an event pair either (a pair taken for
     # a launch that never happens reports a stale duration after the pool's next rewind)
-    tiny = torch.rand((1, 24, 24, 3), device="cuda") * 255
-    wm_tiny = np.zeros((1, 24 * 24 // 64), np.uint8)
-    e3.svd_encode_yuv(tiny, wm_tiny, scale=15, blk=8)
-    e3.svd_decode_yuv(tiny, scale=15, blk=8)
+    tiny = torch.rand((1, 12, 12, 3), device="cuda") * 255          # ((12 / 4) * 2) / 8 = 0 tiles of 16x16, one 8x8 tile
+    wm_tiny = np.zeros((1, 12 * 12 // 64), np.uint8)
+    e3.svd_encode_yuv(tiny, wm_tiny, scale=15, blk=8)                 # (its decode has H*W//256 = 0 bits to return: nothing to call)
     assert t3.durations() == [] and t3.collect()["svd"]["launches"] == 0
     e3.svd_encode_yuv(tiny, wm_tiny, scale=15, blk=4)                 # blk = 4 has 8x8 tiles there: one launch, one pair
     assert t3.collect()["svd"]["launches"] == 1
