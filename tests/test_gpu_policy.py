@@ -155,7 +155,10 @@ def test_fast_readout_equals_float64_for_every_block(eng, alpha):
     H, W = 1080, 1920
     N = H * W // 64
     frames = synthetic_frames(4, H, W, seed=2000)                        # brightness offsets cycle: dark / bright / ramp branches
-    frames = torch.cat([frames, cuda(natural_frame()[None])])
+    rng = np.random.default_rng(77)
+    extreme = np.stack([rng.integers(lo, hi + 1, size=(H, W, 3), dtype=np.uint8) for lo, hi in
+                        ((0, 12), (16, 30), (250, 255), (255, 255), (84, 96))])      # m < 15 / m < 25 branches, mean -> 255 (the
+    frames = torch.cat([frames, cuda(natural_frame()[None]), cuda(extreme)])         # span's reciprocal explodes), saturated white, mean at the 90 clamp
     wm = orc.shuffle_generate(P8, (1, N), 0)
     marked = eng.embed(frames, wm, alpha=20.0)                           # lattice points for alpha = 20: exact ties for that alpha's read-out
     both = torch.cat([frames, marked])
