@@ -239,6 +239,18 @@ def test_bench_placement_helpers_without_a_gpu(tmp_path, monkeypatch):
         os.sched_setaffinity(0, before)
         none = bench.bind_to_gpu_numa([0, 1, 2], 2)         # a GPU that reports no node
         assert not none["bound"] and "no NUMA node" in none["note"] and os.sched_getaffinity(0) == before
+        # device i of the process = entry i of HIP_VISIBLE_DEVICES (applied on top of ROCR_VISIBLE_DEVICES): rank 0 -> physical GPU 2 (no node)
+        monkeypatch.setattr(bench, "gpu_numa_nodes", lambda: [0, 0, -1, 0])
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+        remapped = [bench.bind_to_gpu_numa([0, 1], r) for r in (0, 1)]
+        assert remapped[0]["gpu"] == 2 and not remapped[0]["bound"] and remapped[1]["gpu"] == 0 and remapped[1]["bound"]
+        os.sched_setaffinity(0, before)
+        monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3,1,0")                  # HIP's list indexes ROCR's: "2,0" -> physical 0 and 3
+        both = bench.bind_to_gpu_numa([0, 1], 1)
+        assert both["gpu"] == 3 and both["bound"] and both["ranks_on_node"] == 2
+        os.sched_setaffinity(0, before)
+        monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+        monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
         monkeypatch.setattr(bench, "gpu_numa_nodes", lambda: [])
         assert not bench.bind_to_gpu_numa([0], 0)["bound"]   # no topology at all: an error text, no exception
     finally:
