@@ -260,3 +260,55 @@ def test_bench_placement_helpers_without_a_gpu(tmp_path, monkeypatch):
     bench.inject_failure("second_pass", 0)
     with pytest.raises(RuntimeError, match="rank 1 at second_pass"):
         bench.inject_failure("second_pass", 1)
+
+
+def _load_bench():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_env_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    return bench
+
+
+def test_both_launch_paths_give_the_ranks_the_same_environment(monkeypatch):
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, which RCCL's cross-process buffer sharing needs on this
+    pool's host driver) was set only for ranks bench.py started itself.  Now both paths go through bench.rank_environment:
+    the child launcher's environment (self-launch) and every rank's own os.environ before `import torch` (any launcher)."""
+    import inspect
+    bench = _load_bench()
+    assert bench.RANK_ENV == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env = {}
+    assert bench.rank_environment(env, 1) == {"HSA_ENABLE_IPC_MODE_LEGACY": None} and env == {}          # one rank: nothing to share
+    assert bench.rank_environment(env, 2) == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"} and env == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    mine = {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}                                                         # an explicit choice of the caller stands
+    assert bench.rank_environment(mine, 8) == {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}
+    # path 1: bench.py starts its own ranks -- the environment handed to the child torch.distributed.run
+    seen = {}
+
+    class FakeChild:
+        stdout = []
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, env=None, **kw):
+        seen.update(cmd=cmd, env=env)
+        return FakeChild()
+    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    from types import SimpleNamespace
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(SimpleNamespace(gpus=2))
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["OFMK_BENCH_SELF_LAUNCHED"] == "1"
+    assert "torch.distributed.run" in seen["cmd"] and "127.0.0.1" in seen["cmd"]
+    # path 2: ranks started by an outside launcher -- main() applies the same function to os.environ BEFORE torch is imported
+    src = inspect.getsource(bench.main)
+    assert 0 < src.index("rank_environment(os.environ, env_world)") < src.index("import torch")
+    assert src.index("launch_ranks(a)") < src.index("rank_environment(os.environ, env_world)")

@@ -1,7 +1,7 @@
 """GPU tests of round 5's scheduling and scratch changes (through the C ABI, ctypes):
 
-  * the tile-order policy: a default engine measures nothing, whatever batch lengths it is fed; calibration is opt-in, per size
-    bucket, under a lock, with a margin and a per-process budget;
+  * the tile-order policy: no engine measures anything, whatever batch lengths it is fed -- the library's static rule on the
+    launch size decides unless an order is forced (round 6 removed the opt-in calibration);
   * the frame mean from per-tile partial sums (no zero-fill dispatch, no atomics): stale scratch must never leak into a result,
     whatever the launch shape (ragged tiles, chunks, sizes that are no multiple of 8).  Oracle for the arithmetic itself:
     tests/test_gpu_parity.py (CPU oracle and the reference-run golden vectors), which runs on the same kernels.
@@ -72,7 +72,7 @@ def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
     """VERDICT r4 item 1 / ADVICE r4: round 4's default engine calibrated the tile order on the first large call of every exact
     launch shape (0.25-0.8 s and ~256 repeats of the caller's call each).  Now: twelve distinct batch lengths >= 33 frames of
     1080p through a DEFAULT engine cost what they cost through an engine with a forced order -- under 100 ms of hidden time in
-    all -- leave no calibration record, and give the forced engine's results."""
+    all -- and give the forced engine's results.  (Rounds 4-5 also kept an opt-in calibration mode; removed in round 6.)"""
     import torch
     from offmark import engine as E
     from offmark.synthetic import synthetic_frames
@@ -82,8 +82,6 @@ def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
     out = torch.empty_like(frames)
     wm = cuda(orc.shuffle_generate(P8, (1, H * W // 64), 0).astype(np.uint8))
     perm = cuda(_perm(8).astype(np.int32))
-    E._TILE_ORDER.clear()
-    spent0 = E._CALIBRATION_SPENT_MS[0]
 
     def run(e):
         got = []
@@ -100,7 +98,7 @@ def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
         e.embed_detect(frames[:33], wm, L=8, out=out[:33])
     t_forced, ref = run(forced)
     t_default, got = run(default)
-    assert not E._TILE_ORDER and E._CALIBRATION_SPENT_MS[0] == spent0
+    assert not hasattr(E, "_TILE_ORDER") and not hasattr(default, "calibrate_tile_order")     # the measuring machinery is gone
     assert t_default < t_forced + 0.100, (t_default, t_forced)
     for (m, order, p, c), (_, _, p_r, c_r) in zip(got, ref):
         assert order == ("xcd" if m >= 192 else "linear"), (m, order)
@@ -108,69 +106,3 @@ def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
     print(f"12 batch lengths: default engine {1e3 * t_default:.1f} ms, forced order {1e3 * t_forced:.1f} ms")
 
 
-def test_calibrate_mode_is_bucketed_locked_and_budgeted(eng):
-    """tile_order="calibrate" (opt-in): one measurement per (device, kernel, log2 size bucket) -- a second batch length of the
-    same bucket measures nothing --, and none at all once the process's calibration budget is spent."""
-    import torch
-    from offmark import engine as E
-    from offmark.synthetic import synthetic_frames
-    H, W = 1080, 1920
-    frames = synthetic_frames(60, H, W, seed=32)
-    out = torch.empty_like(frames)
-    wm = cuda(orc.shuffle_generate(P8, (1, H * W // 64), 0).astype(np.uint8))
-    E._TILE_ORDER.clear()
-    saved = (E._CALIBRATION_BUDGET_MS, E._CALIBRATION_SPENT_MS[0])
-    try:
-        E._CALIBRATION_SPENT_MS[0] = 0.0
-        e = type(eng)(tile_order="calibrate")
-        a = e.embed_detect(frames[:48], wm, L=8, out=out[:48])[1].clone()
-        assert len(E._TILE_ORDER) == 1 and e.tile_order_info["policy"] == "calibrated"
-        spent = E._CALIBRATION_SPENT_MS[0]
-        assert 0 < spent < 1500
-        e.embed_detect(frames[:60], wm, L=8, out=out[:60])              # 48 and 60 frames share a bucket (2^28 <= bytes < 2^29)
-        assert len(E._TILE_ORDER) == 1 and E._CALIBRATION_SPENT_MS[0] == spent
-        E._TILE_ORDER.clear()
-        E._CALIBRATION_BUDGET_MS = 0.0                                   # budget spent: falls back to the static rule, no stall
-        t0 = time.perf_counter()
-        b = e.embed_detect(frames[:48], wm, L=8, out=out[:48])[1]
-        torch.cuda.synchronize()
-        assert not E._TILE_ORDER and time.perf_counter() - t0 < 0.2 and e.tile_order_info["policy"] == "static rule"
-        assert torch.equal(a, b)
-    finally:
-        E._CALIBRATION_BUDGET_MS, E._CALIBRATION_SPENT_MS[0] = saved
-        E._TILE_ORDER.clear()
-
-
-@pytest.mark.parametrize("alpha", [20.0, 3.7, 0.05, 5.0e-4, 2.0e6])
-def test_fast_readout_equals_float64_for_every_block(eng, alpha):
-    """The detect hot path reads a block's bit from a float32 estimate of C21 / (alpha * tex * lum) wherever that estimate is
-    provably on the same side of every rounding boundary as the float64 quotient, and from the float64 chain elsewhere
-    (csrc/readout.hiph).  Independent check, every block of full frames: the debug-plane kernel (float64 throughout) gives each
-    block's C21 and step; the reference's read-out on those, in float64 on the host (dct_decoder.py:24: around(c21/step) % 2 == 1),
-    must give the detect path's bit for ALL blocks -- no budget.  alpha = 0.05 makes |x| ~ 10^2..10^3, so that thousands of
-    blocks fall inside the guard band and take the exact path; 5e-4 and 2e6 are outside the fast path's alpha range altogether."""
-    import torch
-    from conftest import natural_frame
-    from offmark.synthetic import synthetic_frames
-    H, W = 1080, 1920
-    N = H * W // 64
-    frames = synthetic_frames(4, H, W, seed=2000)                        # brightness offsets cycle: dark / bright / ramp branches
-    rng = np.random.default_rng(77)
-    extreme = np.stack([rng.integers(lo, hi + 1, size=(H, W, 3), dtype=np.uint8) for lo, hi in
-                        ((0, 12), (16, 30), (250, 255), (255, 255), (84, 96))])      # m < 15 / m < 25 branches, mean -> 255 (the
-    frames = torch.cat([frames, cuda(natural_frame()[None]), cuda(extreme)])         # span's reciprocal explodes), saturated white, mean at the 90 clamp
-    wm = orc.shuffle_generate(P8, (1, N), 0)
-    marked = eng.embed(frames, wm, alpha=20.0)                           # lattice points for alpha = 20: exact ties for that alpha's read-out
-    both = torch.cat([frames, marked])
-    counts, bits = eng.detect(both, 8, alpha=alpha, want_bits=True)
-    bits = bits.cpu().numpy()
-    counts = counts.cpu().numpy()
-    total_in_band = 0
-    for i in range(both.shape[0]):
-        planes = eng.debug_planes(both[i], alpha=alpha)
-        x = planes["c21_pre"].astype(np.float64).reshape(-1) / planes["step"].reshape(-1)
-        want = (np.around(x) % 2 == 1).astype(np.uint8)
-        assert np.array_equal(bits[i], want), (alpha, i, int((bits[i] != want).sum()))
-        assert np.array_equal(counts[i], want.reshape(-1, 8).sum(axis=0))
-        total_in_band += int((0.5 - np.abs(x - np.around(x)) <= 4e-6 * (np.abs(x) + 1)).sum())
-    print(f"alpha {alpha}: {total_in_band} of {both.shape[0] * N} blocks inside the guard band (float64 path)")

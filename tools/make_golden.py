@@ -6,6 +6,10 @@ Run in the build container only (needs /root/reference):  python tools/make_gold
   and run as they are -> fully pinned vectors.
 * dct_encoder / dct_decoder / video.embedder import ``cv2``; tools/standins supplies
   dct / idct / cvtColor from the oracle primitives (OpenCV arithmetic itself unpinned).
+* ``--standin scipy`` runs the 16 DCT cases and the 13 blk-4 DwtDctSvd cases a second time with
+  tools/standins_scipy -- ``scipy.fft.dctn/idctn(norm="ortho")``, plain-NumPy ``cvtColor``, closed-form
+  Haar: primitives the oracle did NOT supply -- into tests/golden_scipy/.  Those vectors differ from the
+  oracle's by float rounding only; tests/test_golden_scipy.py compares at the stated budgets.
 The reference's text is never copied: only inputs and outputs are stored.
 The container's numpy is 2.x, so the captured texture-mask values follow NEP 50 promotion
 (``promotion="nep50"`` in the oracle).
@@ -18,7 +22,12 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, os.path.join(HERE, "standins"))
+STANDIN = "oracle"
+if "--standin" in sys.argv:
+    STANDIN = sys.argv[sys.argv.index("--standin") + 1]
+    del sys.argv[sys.argv.index("--standin"):sys.argv.index("--standin") + 2]
+    assert STANDIN in ("oracle", "scipy"), STANDIN
+sys.path.insert(0, os.path.join(HERE, "standins_scipy" if STANDIN == "scipy" else "standins"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, "/root/reference/src")
 
@@ -35,7 +44,7 @@ from offmark.video.embedder import Embedder  # noqa: E402
 from offmark.embed.dwt_dct_svd_encoder import DwtDctSvdEncoder  # noqa: E402  (needs the pywt + cv2 stand-ins)
 from offmark.extract.dwt_dct_svd_decoder import DwtDctSvdDecoder  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.path.join(ROOT, "tests", "golden_scipy" if STANDIN == "scipy" else "golden")
 os.makedirs(OUT, exist_ok=True)
 logging.disable(logging.CRITICAL)
 
@@ -177,6 +186,18 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--round3":
         svd_blk8_cases()
         return
+    if STANDIN == "scipy":      # second fixture set: the DCT cases and the blk-4 DwtDctSvd cases only, no digests
+        dct_and_svd4_cases()
+        svd_scale_cases()
+        return
+    dct_and_svd4_cases()
+    full_frame_digest_and_payload_codecs()
+    svd_scale_cases()
+    grayscale_at_scale_digests()
+    svd_blk8_cases()
+
+
+def dct_and_svd4_cases():
     P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
     run_svd_case("syn_64x96", orc.synthetic_frame(64, 96, 2), P8, 0, store_yuv=True)
     run_svd_case("syn_240x320", orc.synthetic_frame(240, 320, 1001), P8, 0)
@@ -200,6 +221,20 @@ def main():
         run_case(f"frame63_crop{n}_L8_k0_a20", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0, 20)
     for n, (y, x) in enumerate([(300, 600), (700, 1200)]):
         run_svd_case(f"frame63_crop{n}", np.ascontiguousarray(nat[y:y + 128, x:x + 128]), P8, 0)
+    qr = np.asarray(Image.open("/root/reference/tests/media/wms/qr.jpeg").convert("L"))
+    run_case("frame63_crop_qr_k0_a20", np.ascontiguousarray(nat[256:256 + 256, 512:512 + 384]), qr, 0, 20,
+             image_payload=True)
+    # edge cases
+    run_case("edge_black_64x64", np.zeros((64, 64, 3), np.uint8), P8, 0, 20)
+    run_case("edge_white_64x64", np.full((64, 64, 3), 255, np.uint8), P8, 0, 20)
+    run_case("edge_gray_64x64", np.full((64, 64, 3), 128, np.uint8), P8, 0, 20)
+    run_case("edge_const_payload_64x96", orc.synthetic_frame(64, 96, 9), np.ones(8, dtype=np.int64), 0, 20)
+
+
+def full_frame_digest_and_payload_codecs():
+    from PIL import Image
+    P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    nat = np.asarray(Image.open("/root/reference/tests/media/imgs/frame63.jpeg").convert("RGB"))
     # the whole 1920x1080 natural frame: too large to store its outputs, so store their SHA-256 digests
     import hashlib
     enc, dec = DctEncoder(alpha=20), DctDecoder(alpha=20)
@@ -213,14 +248,6 @@ def main():
                         raw_bits_sha256=np.frombuffer(hashlib.sha256(raw.astype(np.uint8).tobytes()).digest(), np.uint8),
                         raw_ber=np.float64(np.mean(raw.reshape(-1) != wm.reshape(-1))), degenerated=out)
     print(f"frame63_full_digest          1080x1920 raw_ber={np.mean(raw.reshape(-1) != wm.reshape(-1)):.4f} payload_ok={np.array_equal(out, P8)}")
-    qr = np.asarray(Image.open("/root/reference/tests/media/wms/qr.jpeg").convert("L"))
-    run_case("frame63_crop_qr_k0_a20", np.ascontiguousarray(nat[256:256 + 256, 512:512 + 384]), qr, 0, 20,
-             image_payload=True)
-    # edge cases
-    run_case("edge_black_64x64", np.zeros((64, 64, 3), np.uint8), P8, 0, 20)
-    run_case("edge_white_64x64", np.full((64, 64, 3), 255, np.uint8), P8, 0, 20)
-    run_case("edge_gray_64x64", np.full((64, 64, 3), 128, np.uint8), P8, 0, 20)
-    run_case("edge_const_payload_64x96", orc.synthetic_frame(64, 96, 9), np.ones(8, dtype=np.int64), 0, 20)
     # payload codecs alone (numpy-only reference modules, no stand-in involved)
     rows = {}
     for key in (0, 7, None):
@@ -242,11 +269,6 @@ def main():
                 rows[tag + "_back"] = back
     np.savez_compressed(os.path.join(OUT, "payload_codecs.npz"), **rows)
     print("payload_codecs", len(rows) // 4, "cases")
-
-
-    svd_scale_cases()
-    grayscale_at_scale_digests()
-    svd_blk8_cases()
 
 
 if __name__ == "__main__":

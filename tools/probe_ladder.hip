@@ -1,0 +1,761 @@
+// Hardware probe (not product code): the LADDER from the engine's bare access pattern to the real frame kernels, and the
+// candidate restructurings of those kernels, all timed interleaved in one process on the same buffers.
+//   build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/probe_ladder.hip -o tools/bin/probe_ladder
+//   run:   tools/bin/probe_ladder [frames=300] [rounds=4] [reps=10]          timing table, both tile orders
+//          tools/bin/probe_ladder pmc <0|8> [frames]                         two launches of every rung in ONE tile order (for rocprofv3 --pmc)
+// The product translation unit is included as it stands, so the "real" rungs ARE the shipped kernels and every other rung
+// can use the shipped device functions.
+#include "../video-fingerprinting_amd/csrc/offmark_kernels.hip"
+
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace lad {
+using namespace ofmk;
+
+// ------------------------------------------------------------------------------------------
+// synthetic frames: smooth base + per-128x128-tile noise amplitude + per-frame brightness (SURVEY 8d's recipe in spirit)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ void gen_frames(uint8_t *p, int H, int W, int n) {
+    const size_t total = (size_t)n * H * W * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = i / 3;
+        const int ch = (int)(i - px * 3);
+        const int f = (int)(px / ((size_t)H * W));
+        const int r = (int)(px - (size_t)f * H * W);
+        const int y = r / W, x = r - y * W;
+        const float base = 128.f + 70.f * __sinf(0.004f * x + 0.9f * ch + 0.37f * f) * __cosf(0.006f * y + 0.5f * ch);
+        const int amp_sel = ((x >> 7) + (y >> 7) + f) & 3;
+        const float amp = amp_sel == 0 ? 0.f : amp_sel == 1 ? 2.f : amp_sel == 2 ? 8.f : 24.f;
+        const float nz = ((float)(hash32((unsigned)i * 2654435761u + 12345u) & 0xffff) / 65535.f - 0.5f) * 2.f * amp;
+        const float off = (float)(((f & 3) - 1.5f) * 40.f);
+        float v = base + nz + off;
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        p[i] = (uint8_t)__float2int_rn(v);
+    }
+}
+__global__ void gen_bits(uint8_t *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = (uint8_t)(hash32((unsigned)i + 99u) & 1u);
+}
+// order-independent checksum (sum of 64-bit mixes), for bit-identity of whole buffers
+__global__ void checksum_kernel(const uint32_t *p, size_t n_words, unsigned long long *acc) {
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long v = ((unsigned long long)p[i] + 0x9E3779B97F4A7C15ull) * (0xBF58476D1CE4E5B9ull ^ (unsigned long long)i);
+        v ^= v >> 29;
+        s += v * 0x94D049BB133111EBull;
+    }
+    atomicAdd(acc, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// bottom-up rungs: bare pattern, + frame-mean prologue, + record loads and the float64 scalar stage, + a dependent VALU chain
+// ------------------------------------------------------------------------------------------
+// RUNG 0: load 8 rows, store 8 rows (the engine's access pattern, nothing else)
+// RUNG 1: + frame_lum_to_lds + barrier (the per-workgroup prologue of the mark kernel)
+// RUNG 2: + the three record loads, the watermark byte and mark_delta (float64 scalar stage)
+// RUNG 3: + FILL dependent fmas per pixel, each row stored as soon as it is done (the real kernel's shape, no real arithmetic)
+// RUNG 4: as 3, but the 8 finished rows are held and stored back to back at the end (the bare probe's store shape)
+template <int RUNG, int FILL, int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void rung_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, Geom g, MarkArgs m,
+                                                                unsigned zero) {
+    __shared__ FrameLum s_lum;
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!xcd_tile(g.xcds, tiles, g.frames, f, bx)) return;
+    const int c = bx * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    const int cc = valid ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<true>(in + off + (size_t)r * pitch);
+    float d = 0.f;
+    if constexpr (RUNG >= 1) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) forget(raw[r]);
+        frame_lum_to_lds(m.ysum, f, tiles, g.nblk, &s_lum);
+        __syncthreads();
+        d = (float)s_lum.mean;
+    }
+    if (!valid) return;
+    if constexpr (RUNG >= 2) {
+        const float *r = m.rec + (size_t)f * g.nblk + cc;
+        const int row = wm_row_of(m.wm_row, f, m.n_wm);
+        d = mark_delta(r[0], r[g.plane], r[2 * g.plane], s_lum, m.alpha, m.wm[(size_t)row * m.N + cc]);
+    }
+    const unsigned dz = __float_as_uint(d) & zero;       // zero == 0 at run time: the stores depend on d, the bytes do not change
+    if constexpr (RUNG <= 2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            Px8 o = raw[r];
+            o.w[0] ^= dz;
+            store_px8<true>(out + off + (size_t)r * pitch, o);
+        }
+    } else {
+        Px8 hold[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float a[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) a[x] = px_byte(raw[r], 3 * x) + d;
+#pragma unroll
+            for (int k = 0; k < FILL; ++k) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) a[x] = fmaf(a[x], 1.0001f, d);
+            }
+            Px8 o = raw[r];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) o.w[x] ^= (__float_as_uint(a[x] + a[(x + 2) & 7]) & zero);
+            if constexpr (RUNG == 3) store_px8<true>(out + off + (size_t)r * pitch, o);
+            else hold[r] = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (RUNG == 4) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) store_px8<true>(out + off + (size_t)r * pitch, hold[r]);
+        }
+    }
+}
+
+// read-only form of rung 0 (what bounds analyze)
+__global__ __launch_bounds__(kThreads, 4) void read_rung_kernel(const uint8_t *__restrict__ in, Geom g, unsigned *sink) {
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!xcd_tile(g.xcds, tiles, g.frames, f, bx)) return;
+    const int c = bx * kThreads + threadIdx.x;
+    const int cc = c < g.nblk ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<true>(in + off + (size_t)r * pitch);
+    unsigned x = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int w = 0; w < 6; ++w) x ^= raw[r].w[w];
+    if (x == 0x9E3779B9u && (blockIdx.x ^ threadIdx.x) == 0x5bd1e995u) sink[0] = x;
+}
+
+// ------------------------------------------------------------------------------------------
+// top-down rung: the REAL non-fused mark kernel with one thing taken away
+// ------------------------------------------------------------------------------------------
+// VAR 1: FrameLum read from a per-frame array computed beforehand (no prologue, no barrier, no LDS)
+// VAR 2: the 8 marked rows held and stored back to back at the end
+// VAR 3: both
+template <int VAR, bool FUSED, int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void mark_var_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, Geom g, MarkArgs m,
+                                                                    const FrameLum *__restrict__ lum, float *rec_out,
+                                                                    unsigned long long *__restrict__ ysum_out) {
+    __shared__ FrameLum s_lum;
+    __shared__ long long s_part[kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!xcd_tile(g.xcds, tiles, g.frames, f, bx)) return;
+    const int c = bx * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    const int cc = valid ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<true>(in + off + (size_t)r * pitch);
+    FrameLum fl;
+    if constexpr (VAR & 1) {
+        fl = lum[f];                       // wave-uniform address: scalar loads
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) forget(raw[r]);
+        frame_lum_to_lds(m.ysum, f, tiles, g.nblk, &s_lum);
+        __syncthreads();
+        fl = s_lum;
+    }
+    if (!FUSED && !valid) return;
+    float R[8][8], u1[4];
+    float d;
+    {
+        const float *r = m.rec + (size_t)f * g.nblk + cc;
+        const int row = wm_row_of(m.wm_row, f, m.n_wm);
+        d = mark_delta(r[0], r[g.plane], r[2 * g.plane], fl, m.alpha, m.wm[(size_t)row * m.N + cc]);
+    }
+    if constexpr (VAR & 2) {
+        // mark_rows with the stores moved to the end: the rows go to a scratch "pitch" of registers
+        Px8 hold[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const Px8 &px = raw[r];
+            const float dr = d * c2_of(r);
+            Px8 o = px;
+            float yv[8], uv[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float c0 = px_byte(px, 3 * x), c1 = px_byte(px, 3 * x + 1), c2 = px_byte(px, 3 * x + 2);
+                const float t2 = c2 * KY2;
+                const float y = fmaf(c0, KY0, fmaf(c1, KY1, t2));
+                const float u = fmaf(c0 - y, KU, KDELTA);
+                const float v = fmaf(c2 - y, KV, KDELTA);
+                const float u2 = fmaf(dr, c1_of(x), u);
+                const float ud = u2 - KDELTA, vd = v - KDELTA;
+                o.w[(3 * x) >> 2] = put_u8(fmaf(ud, KI_B, y), (3 * x) & 3, o.w[(3 * x) >> 2]);
+                o.w[(3 * x + 1) >> 2] = put_u8(fmaf(vd, KI_GV, fmaf(ud, KI_GU, y)), (3 * x + 1) & 3, o.w[(3 * x + 1) >> 2]);
+                if constexpr (FUSED) {
+                    const float n0 = px_byte(o, 3 * x), n1 = px_byte(o, 3 * x + 1);
+                    yv[x] = fmaf(n0, KY0, fmaf(n1, KY1, t2));
+                    uv[x] = fmaf(n0 - yv[x], KU, KDELTA);
+                }
+            }
+            hold[r] = o;
+            if constexpr (FUSED) {
+                fold_u1(u1, r, proj1(uv));
+                dct8s(yv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) R[r][k] = yv[k];
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) store_px8<true>(out + off + (size_t)r * pitch, hold[r]);
+        }
+    } else {
+        mark_rows<true, FUSED>(raw, d, valid, out + off, pitch, R, u1);
+    }
+    if constexpr (FUSED) {
+        const BlockFeat ft = block_features(R, u1);
+        emit_block(ft, valid, f, c, bx, tiles, g, rec_out, ysum_out, s_part);
+    }
+}
+
+__global__ void lum_kernel(const unsigned long long *__restrict__ ysum, int tiles, int nblk, FrameLum *__restrict__ lum) {
+    __shared__ FrameLum s;
+    frame_lum_to_lds(ysum, blockIdx.x, tiles, nblk, &s);
+    __syncthreads();
+    if (threadIdx.x == 0) lum[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// candidate: K tiles per workgroup, the NEXT tile's pixels loaded before the current tile is computed and stored
+// ------------------------------------------------------------------------------------------
+struct Pipe { int K; int contig; };
+
+__device__ __forceinline__ bool pipe_tile(const Geom &g, const Pipe &pp, int tiles, int k, int &f, int &bx) {
+    const unsigned G = (unsigned)tiles * (unsigned)g.frames;
+    const unsigned X = g.xcds > 1 ? (unsigned)g.xcds : 1u;
+    const unsigned per = (G + X - 1) / X;
+    const unsigned nw = (per + (unsigned)pp.K - 1) / (unsigned)pp.K;     // workgroups per XCD
+    const unsigned xcd = blockIdx.x % X, i = blockIdx.x / X;
+    if (k >= pp.K || i >= nw) return false;
+    const unsigned local = pp.contig ? i * (unsigned)pp.K + (unsigned)k : (unsigned)k * nw + i;
+    if (local >= per) return false;
+    const unsigned t = xcd * per + local;
+    if (t >= G) return false;
+    f = (int)(t / (unsigned)tiles);
+    bx = (int)(t - (unsigned)f * (unsigned)tiles);
+    return true;
+}
+static unsigned pipe_grid(int nblk, int frames, int xcds, int K) {
+    const unsigned tiles = (unsigned)((nblk + kThreads - 1) / kThreads);
+    const unsigned G = tiles * (unsigned)frames;
+    const unsigned X = xcds > 1 ? (unsigned)xcds : 1u;
+    const unsigned per = (G + X - 1) / X;
+    const unsigned nw = (per + (unsigned)K - 1) / (unsigned)K;
+    return nw * X;
+}
+
+struct TilePos { size_t off; int c; bool valid; int cc; };
+__device__ __forceinline__ TilePos tile_pos(const Geom &g, int f, int bx) {
+    TilePos p;
+    p.c = bx * kThreads + threadIdx.x;
+    p.valid = p.c < g.nblk;
+    p.cc = p.valid ? p.c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(p.cc, g.wb, g.inv_wb, bi, bj);
+    p.off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    return p;
+}
+__device__ __forceinline__ void load_tile(Px8 (&raw)[8], const uint8_t *__restrict__ in, const Geom &g, int f, int bx) {
+    const TilePos p = tile_pos(g, f, bx);
+    const int pitch = g.W * 3;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<true>(in + p.off + (size_t)r * pitch);
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void mark_tile(const Px8 (&raw)[8], uint8_t *__restrict__ out, const Geom &g, const MarkArgs &m, int tiles, int f, int bx,
+                                          const FrameLum &fl, float *rec_out, unsigned long long *__restrict__ ysum_out, long long *s_part) {
+    const TilePos p = tile_pos(g, f, bx);
+    float R[8][8], u1[4];
+    float d;
+    {
+        const float *r = m.rec + (size_t)f * g.nblk + p.cc;
+        const int row = wm_row_of(m.wm_row, f, m.n_wm);
+        d = mark_delta(r[0], r[g.plane], r[2 * g.plane], fl, m.alpha, m.wm[(size_t)row * m.N + p.cc]);
+    }
+    mark_rows<true, FUSED>(raw, d, p.valid, out + p.off, g.W * 3, R, u1);
+    if constexpr (FUSED) {
+        const BlockFeat ft = block_features(R, u1);
+        emit_block(ft, p.valid, f, p.c, bx, tiles, g, rec_out, ysum_out, s_part);
+    }
+}
+
+template <bool FUSED, int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void mark_pipe_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, Geom g, MarkArgs m, Pipe pp,
+                                                                     float *rec_out, unsigned long long *__restrict__ ysum_out) {
+    __shared__ FrameLum s_lum[2];
+    __shared__ long long s_part[2][kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!pipe_tile(g, pp, tiles, 0, f, bx)) return;
+    Px8 A[8], B[8];
+    load_tile(A, in, g, f, bx);
+    FrameLum fl;
+    int lum_f = -1, par = 0;
+    for (int k = 0;; k += 2) {
+        int fn = 0, bxn = 0;
+        bool more = pipe_tile(g, pp, tiles, k + 1, fn, bxn);
+        if (more) load_tile(B, in, g, fn, bxn);
+        if (f != lum_f) {                                   // workgroup-uniform
+            frame_lum_to_lds(m.ysum, f, tiles, g.nblk, &s_lum[par]);
+            __syncthreads();
+            fl = s_lum[par];
+            par ^= 1;
+            lum_f = f;
+        }
+        mark_tile<FUSED>(A, out, g, m, tiles, f, bx, fl, rec_out, ysum_out, s_part[0]);
+        if (!more) break;
+        f = fn; bx = bxn;
+        more = pipe_tile(g, pp, tiles, k + 2, fn, bxn);
+        if (more) load_tile(A, in, g, fn, bxn);
+        if (f != lum_f) {
+            frame_lum_to_lds(m.ysum, f, tiles, g.nblk, &s_lum[par]);
+            __syncthreads();
+            fl = s_lum[par];
+            par ^= 1;
+            lum_f = f;
+        }
+        mark_tile<FUSED>(B, out, g, m, tiles, f, bx, fl, rec_out, ysum_out, s_part[1]);
+        if (!more) break;
+        f = fn; bx = bxn;
+    }
+}
+
+__device__ __forceinline__ void analyze_tile(const Px8 (&raw)[8], const Geom &g, int tiles, int f, int bx, float *__restrict__ rec,
+                                             unsigned long long *__restrict__ ysum, long long *s_part) {
+    const TilePos p = tile_pos(g, f, bx);
+    float R[8][8], u1[4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float y[8], u[8];
+        row_yu(raw[r], y, u);
+        fold_u1(u1, r, proj1(u));
+        dct8s(y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) R[r][k] = y[k];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const BlockFeat ft = block_features(R, u1);
+    emit_block(ft, p.valid, f, p.c, bx, tiles, g, rec, ysum, s_part);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void analyze_pipe_kernel(const uint8_t *__restrict__ in, Geom g, Pipe pp, float *__restrict__ rec,
+                                                                        unsigned long long *__restrict__ ysum) {
+    __shared__ long long s_part[2][kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!pipe_tile(g, pp, tiles, 0, f, bx)) return;
+    Px8 A[8], B[8];
+    load_tile(A, in, g, f, bx);
+    for (int k = 0;; k += 2) {
+        int fn = 0, bxn = 0;
+        bool more = pipe_tile(g, pp, tiles, k + 1, fn, bxn);
+        if (more) load_tile(B, in, g, fn, bxn);
+        analyze_tile(A, g, tiles, f, bx, rec, ysum, s_part[0]);
+        if (!more) break;
+        f = fn; bx = bxn;
+        more = pipe_tile(g, pp, tiles, k + 2, fn, bxn);
+        if (more) load_tile(A, in, g, fn, bxn);
+        analyze_tile(B, g, tiles, f, bx, rec, ysum, s_part[1]);
+        if (!more) break;
+        f = fn; bx = bxn;
+    }
+}
+
+// bare pattern, pipelined the same way (what the memory system gives this schedule with no arithmetic at all)
+template <bool WRITE>
+__global__ __launch_bounds__(kThreads, 3) void bare_pipe_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, Geom g, Pipe pp, unsigned *sink) {
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!pipe_tile(g, pp, tiles, 0, f, bx)) return;
+    Px8 A[8], B[8];
+    load_tile(A, in, g, f, bx);
+    unsigned x = 0;
+    auto flush = [&](const Px8 (&raw)[8], int ff, int bb) {
+        const TilePos p = tile_pos(g, ff, bb);
+        if (WRITE) {
+            if (p.valid) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) store_px8<true>(out + p.off + (size_t)r * (g.W * 3), raw[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) x ^= raw[r].w[w];
+        }
+    };
+    for (int k = 0;; k += 2) {
+        int fn = 0, bxn = 0;
+        bool more = pipe_tile(g, pp, tiles, k + 1, fn, bxn);
+        if (more) load_tile(B, in, g, fn, bxn);
+        flush(A, f, bx);
+        if (!more) break;
+        f = fn; bx = bxn;
+        more = pipe_tile(g, pp, tiles, k + 2, fn, bxn);
+        if (more) load_tile(A, in, g, fn, bxn);
+        flush(B, f, bx);
+        if (!more) break;
+        f = fn; bx = bxn;
+    }
+    if (!WRITE && x == 0x9E3779B9u && (blockIdx.x ^ threadIdx.x) == 0x5bd1e995u) sink[0] = x;
+}
+
+// ------------------------------------------------------------------------------------------
+// candidate 2: the rolling row prefetch carried ACROSS tiles -- P rows ahead at all times, the next tile's first rows in flight
+// while the current tile's column transforms, features and stores run.  Costs 6 VGPRs per row ahead instead of 48 for a whole tile.
+// ------------------------------------------------------------------------------------------
+template <bool FUSED>
+__device__ __forceinline__ void mark_row(int r, const Px8 &px, float d, bool valid, uint8_t *__restrict__ out_row, float (&R)[8][8], float (&u1)[4]) {
+    const float dr = d * c2_of(r);
+    Px8 o = px;
+    float yv[8], uv[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        const float c0 = px_byte(px, 3 * x), c1 = px_byte(px, 3 * x + 1), c2 = px_byte(px, 3 * x + 2);
+        const float t2 = c2 * KY2;
+        const float y = fmaf(c0, KY0, fmaf(c1, KY1, t2));
+        const float u = fmaf(c0 - y, KU, KDELTA);
+        const float v = fmaf(c2 - y, KV, KDELTA);
+        const float u2 = fmaf(dr, c1_of(x), u);
+        const float ud = u2 - KDELTA, vd = v - KDELTA;
+        o.w[(3 * x) >> 2] = put_u8(fmaf(ud, KI_B, y), (3 * x) & 3, o.w[(3 * x) >> 2]);
+        o.w[(3 * x + 1) >> 2] = put_u8(fmaf(vd, KI_GV, fmaf(ud, KI_GU, y)), (3 * x + 1) & 3, o.w[(3 * x + 1) >> 2]);
+        if constexpr (FUSED) {
+            const float n0 = px_byte(o, 3 * x), n1 = px_byte(o, 3 * x + 1);
+            yv[x] = fmaf(n0, KY0, fmaf(n1, KY1, t2));
+            uv[x] = fmaf(n0 - yv[x], KU, KDELTA);
+        }
+    }
+    if (valid) store_px8<true>(out_row, o);
+    if constexpr (FUSED) {
+        fold_u1(u1, r, proj1(uv));
+        dct8s(yv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) R[r][k] = yv[k];
+    }
+}
+
+template <bool FUSED, int P, int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void mark_ring_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, Geom g, MarkArgs m, Pipe pp,
+                                                                     float *rec_out, unsigned long long *__restrict__ ysum_out) {
+    __shared__ FrameLum s_lum[2];
+    __shared__ long long s_part[2][kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    const int pitch = g.W * 3;
+    int f, bx;
+    if (!pipe_tile(g, pp, tiles, 0, f, bx)) return;
+    TilePos cur = tile_pos(g, f, bx);
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < P; ++r) raw[r] = load_px8<true>(in + cur.off + (size_t)r * pitch);
+    float ra, rt, rc; int rbit;
+    {
+        const float *q = m.rec + (size_t)f * g.nblk + cur.cc;
+        ra = q[0]; rt = q[g.plane]; rc = q[2 * g.plane];
+        rbit = m.wm[(size_t)wm_row_of(m.wm_row, f, m.n_wm) * m.N + cur.cc];
+    }
+    FrameLum fl;
+    int lum_f = -1, par = 0;
+    for (int k = 0;; ++k) {
+        int fn = f, bxn = bx;
+        const bool more = pipe_tile(g, pp, tiles, k + 1, fn, bxn);
+        TilePos nxt = cur;
+        if (more) nxt = tile_pos(g, fn, bxn);
+        if (f != lum_f) {                                   // workgroup-uniform
+            frame_lum_to_lds(m.ysum, f, tiles, g.nblk, &s_lum[par]);
+            __syncthreads();
+            fl = s_lum[par];
+            par ^= 1;
+            lum_f = f;
+        }
+        const float d = mark_delta(ra, rt, rc, fl, m.alpha, rbit);
+        if (more) {                                         // the next tile's record: in flight for the whole of this tile
+            const float *q = m.rec + (size_t)fn * g.nblk + nxt.cc;
+            ra = q[0]; rt = q[g.plane]; rc = q[2 * g.plane];
+            rbit = m.wm[(size_t)wm_row_of(m.wm_row, fn, m.n_wm) * m.N + nxt.cc];
+        }
+        float R[8][8], u1[4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r + P < 8) raw[r + P] = load_px8<true>(in + cur.off + (size_t)(r + P) * pitch);
+            else if (more) raw[r + P - 8] = load_px8<true>(in + nxt.off + (size_t)(r + P - 8) * pitch);
+            mark_row<FUSED>(r, raw[r], d, cur.valid, out + cur.off + (size_t)r * pitch, R, u1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (FUSED) {
+            const BlockFeat ft = block_features(R, u1);
+            emit_block(ft, cur.valid, f, cur.c, bx, tiles, g, rec_out, ysum_out, s_part[k & 1]);
+        }
+        if (!more) break;
+        f = fn; bx = bxn; cur = nxt;
+    }
+}
+
+template <int P, int WAVES>
+__global__ __launch_bounds__(kThreads, WAVES) void analyze_ring_kernel(const uint8_t *__restrict__ in, Geom g, Pipe pp, float *__restrict__ rec,
+                                                                        unsigned long long *__restrict__ ysum) {
+    __shared__ long long s_part[2][kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    const int pitch = g.W * 3;
+    int f, bx;
+    if (!pipe_tile(g, pp, tiles, 0, f, bx)) return;
+    TilePos cur = tile_pos(g, f, bx);
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < P; ++r) raw[r] = load_px8<true>(in + cur.off + (size_t)r * pitch);
+    for (int k = 0;; ++k) {
+        int fn = f, bxn = bx;
+        const bool more = pipe_tile(g, pp, tiles, k + 1, fn, bxn);
+        TilePos nxt = cur;
+        if (more) nxt = tile_pos(g, fn, bxn);
+        float R[8][8], u1[4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r + P < 8) raw[r + P] = load_px8<true>(in + cur.off + (size_t)(r + P) * pitch);
+            else if (more) raw[r + P - 8] = load_px8<true>(in + nxt.off + (size_t)(r + P - 8) * pitch);
+            float y[8], u[8];
+            row_yu(raw[r], y, u);
+            fold_u1(u1, r, proj1(u));
+            dct8s(y);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) R[r][q] = y[q];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const BlockFeat ft = block_features(R, u1);
+        emit_block(ft, cur.valid, f, cur.c, bx, tiles, g, rec, ysum, s_part[k & 1]);
+        if (!more) break;
+        f = fn; bx = bxn; cur = nxt;
+    }
+}
+
+}  // namespace lad
+
+// ------------------------------------------------------------------------------------------
+#define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #e, hipGetErrorString(e_)); exit(2); } } while (0)
+
+struct Variant { std::string name; double bytes; std::function<void(int xcds)> launch; std::vector<double> ms[2]; };
+
+int main(int argc, char **argv) {
+    using namespace ofmk;
+    using namespace lad;
+    const bool pmc = argc > 1 && std::string(argv[1]) == "pmc";
+    const int pmc_order = pmc && argc > 2 ? atoi(argv[2]) : 0;
+    const int nf = pmc ? (argc > 3 ? atoi(argv[3]) : 300) : (argc > 1 ? atoi(argv[1]) : 300);
+    const int rounds = !pmc && argc > 2 ? atoi(argv[2]) : 4;
+    const int reps = !pmc && argc > 3 ? atoi(argv[3]) : 10;
+    const int H = 1080, W = 1920;
+    const size_t fs = (size_t)H * W * 3, bytes = fs * nf;
+    const int nblk = (H / 8) * (W / 8), N = nblk;
+    uint8_t *in, *out, *out_ref, *wm;
+    CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes)); CK(hipMalloc(&out_ref, bytes)); CK(hipMalloc(&wm, N));
+    const size_t ws_bytes = ofmk_workspace_bytes(nf, H, W);
+    void *wsp, *wsp2; CK(hipMalloc(&wsp, ws_bytes)); CK(hipMalloc(&wsp2, ws_bytes));
+    Workspace ws, ws2;
+    if (carve(wsp, ws_bytes, H, W, nf, ws) || carve(wsp2, ws_bytes, H, W, nf, ws2)) { fprintf(stderr, "carve: %s\n", g_err); return 2; }
+    FrameLum *lum; CK(hipMalloc(&lum, sizeof(FrameLum) * nf));
+    unsigned long long *acc; CK(hipMalloc(&acc, 8));
+    unsigned *sink; CK(hipMalloc(&sink, 16));
+    hipLaunchKernelGGL(gen_frames, dim3(8192), dim3(256), 0, 0, in, H, W, nf);
+    hipLaunchKernelGGL(gen_bits, dim3(64), dim3(256), 0, 0, wm, (size_t)N);
+    CK(hipMemset(out, 0, bytes)); CK(hipMemset(out_ref, 0, bytes));
+    CK(hipDeviceSynchronize());
+
+    Ctx cx; cx.s = 0; cx.t = nullptr; cx.flags = 0; cx.xcds = 8;
+    // records of the input frames: the shipped analyze kernel
+    if (launch_analyze(in, SRC_RGB8, nf, H, W, ws, cx)) { fprintf(stderr, "analyze: %s\n", g_err); return 2; }
+    hipLaunchKernelGGL(lum_kernel, dim3(nf), dim3(64), 0, 0, ws.ysum, ws.tiles, nblk, lum);
+    CK(hipDeviceSynchronize());
+
+    MarkArgs m; m.rec = ws.rec; m.ysum = ws.ysum; m.wm = wm; m.wm_row = nullptr; m.n_wm = 1; m.N = N; m.alpha = 20.0;
+    auto geom = [&](int xcds) { return make_geom(H, W, ws, nf, xcds); };
+    auto cksum = [&](const void *p, size_t nbytes) {
+        CK(hipMemset(acc, 0, 8));
+        hipLaunchKernelGGL(checksum_kernel, dim3(4096), dim3(256), 0, 0, static_cast<const uint32_t *>(p), nbytes / 4, acc);
+        unsigned long long h; CK(hipMemcpy(&h, acc, 8, hipMemcpyDeviceToHost));
+        return h;
+    };
+
+    // ---- reference results of the shipped kernels (fused writes the marked frames' records to ws2.rec / ws2.ysum2)
+    hipLaunchKernelGGL((mark_rgb8_kernel<true, true>), xcd_grid(nblk, nf, 8), dim3(kThreads), 0, 0, in, out_ref, geom(8), m, ws2.rec, ws2.ysum2);
+    CK(hipDeviceSynchronize());
+    const unsigned long long ref_out = cksum(out_ref, bytes), ref_rec = cksum(ws2.rec, ws.plane * kRec * 4), ref_ys = cksum(ws2.ysum2, (size_t)nf * ws.tiles * 8);
+    const unsigned long long ref_arec = cksum(ws.rec, ws.plane * kRec * 4), ref_ays = cksum(ws.ysum, (size_t)nf * ws.tiles * 8);
+    int bad = 0;
+    auto check = [&](const char *what, bool fused_outputs) {
+        CK(hipDeviceSynchronize());
+        const unsigned long long o = cksum(out, bytes);
+        bool ok = o == ref_out;
+        if (fused_outputs) ok = ok && cksum(ws2.rec, ws.plane * kRec * 4) == ref_rec && cksum(ws2.ysum2, (size_t)nf * ws.tiles * 8) == ref_ys;
+        printf("# identical to the shipped kernel's result: %-46s %s\n", what, ok ? "yes" : "NO");
+        if (!ok) ++bad;
+        CK(hipMemset(out, 0, bytes));
+    };
+
+    const double rw = 2.0 * bytes, rd = 1.0 * bytes;
+    const dim3 tb(kThreads);
+    std::vector<Variant> V;
+    auto add = [&](const char *name, double b, std::function<void(int)> fn) { V.push_back(Variant{name, b, fn, {}}); };
+#define RUNG(R, F, WV) [&](int xc) { hipLaunchKernelGGL((rung_kernel<R, F, WV>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, 0u); }
+    add("L0 bare pattern (8 waves/SIMD allowed)", rw, RUNG(0, 0, 8));
+    add("L0 bare pattern, 4 waves/SIMD cap", rw, [&](int xc) { hipLaunchKernelGGL((rung_kernel<0, 0, 8>), xcd_grid(nblk, nf, xc), tb, 36 * 1024, 0, in, out, geom(xc), m, 0u); });
+    add("L0 bare pattern, 3 waves/SIMD cap", rw, [&](int xc) { hipLaunchKernelGGL((rung_kernel<0, 0, 8>), xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, out, geom(xc), m, 0u); });
+    add("L1 + frame-mean prologue + barrier", rw, RUNG(1, 0, 4));
+    add("L2 + records, wm byte, float64 scalar stage", rw, RUNG(2, 0, 4));
+    add("L3 + 20 fma/px chain, row-by-row stores", rw, RUNG(3, 20, 4));
+    add("L4   same chain, 8 rows stored at the end", rw, RUNG(4, 20, 4));
+    add("L3'+ 36 fma/px chain, row-by-row (3 waves)", rw, RUNG(3, 36, 3));
+    add("L4'  same chain, stores at the end (3 waves)", rw, RUNG(4, 36, 3));
+    add("R  real mark (non-fused), shipped", rw, [&](int xc) { hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
+    add("R1 real mark, FrameLum precomputed", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<1, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+    add("R2 real mark, stores at the end", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<2, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+    add("R3 real mark, both", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<3, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+    add("F  real mark+verify (fused), shipped", rw, [&](int xc) { hipLaunchKernelGGL((mark_rgb8_kernel<true, true>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
+    add("F1 fused, FrameLum precomputed", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<1, true, 3>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+    add("F2 fused, stores at the end", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<2, true, 3>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+    add("F3 fused, precomputed + stores at the end", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<3, true, 3>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+#define PIPE_M(FUSED, WV, K, CONTIG) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((mark_pipe_kernel<FUSED, WV>), dim3(pipe_grid(nblk, nf, xc, K)), tb, 0, 0, in, out, geom(xc), m, pp, ws2.rec, ws2.ysum2); }
+    add("P  mark pipelined K=2 contiguous", rw, PIPE_M(false, 3, 2, 1));
+    add("P  mark pipelined K=4 contiguous", rw, PIPE_M(false, 3, 4, 1));
+    add("P  mark pipelined K=4 strided", rw, PIPE_M(false, 3, 4, 0));
+    add("P  mark pipelined K=8 contiguous", rw, PIPE_M(false, 3, 8, 1));
+    add("PF fused pipelined K=2 contiguous", rw, PIPE_M(true, 3, 2, 1));
+    add("PF fused pipelined K=4 contiguous", rw, PIPE_M(true, 3, 4, 1));
+    add("PF fused pipelined K=4 strided", rw, PIPE_M(true, 3, 4, 0));
+    add("PF fused pipelined K=8 contiguous", rw, PIPE_M(true, 3, 8, 1));
+    add("PF fused pipelined K=4 contiguous, 2 waves", rw, PIPE_M(true, 2, 4, 1));
+#define PIPE_B(WRITE, K, CONTIG) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((bare_pipe_kernel<WRITE>), dim3(pipe_grid(nblk, nf, xc, K)), tb, 0, 0, in, out, geom(xc), pp, sink); }
+    add("B  bare copy pipelined K=4 contiguous", rw, PIPE_B(true, 4, 1));
+    add("B  bare copy pipelined K=4 strided", rw, PIPE_B(true, 4, 0));
+    add("B  bare read pipelined K=4 contiguous", rd, PIPE_B(false, 4, 1));
+    add("L0r bare pattern, read only", rd, [&](int xc) { hipLaunchKernelGGL(read_rung_kernel, xcd_grid(nblk, nf, xc), tb, 0, 0, in, geom(xc), sink); });
+    add("L0r bare pattern, read only, 3 WG/CU", rd, [&](int xc) { hipLaunchKernelGGL(read_rung_kernel, xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), sink); });
+    add("A  analyze, shipped (3 WG/CU LDS cap)", rd, [&](int xc) { hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, true>), xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), ws2.rec, ws2.ysum, nullptr, 0); });
+#define PIPE_A(WV, K, CONTIG, LDS) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((analyze_pipe_kernel<WV>), dim3(pipe_grid(nblk, nf, xc, K)), tb, LDS, 0, in, geom(xc), pp, ws2.rec, ws2.ysum); }
+    add("PA analyze pipelined K=2 contiguous", rd, PIPE_A(3, 2, 1, 0));
+    add("PA analyze pipelined K=4 contiguous", rd, PIPE_A(3, 4, 1, 0));
+    add("PA analyze pipelined K=4 strided", rd, PIPE_A(3, 4, 0, 0));
+    add("PA analyze pipelined K=8 contiguous", rd, PIPE_A(3, 8, 1, 0));
+    add("PA analyze pipelined K=4 contiguous, 2 WG/CU", rd, PIPE_A(3, 4, 1, 72 * 1024));
+    add("PA analyze pipelined K=4 contiguous, 4 waves", rd, PIPE_A(4, 4, 1, 0));
+
+#define RING_M(FUSED, P, WV, K, CONTIG) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((mark_ring_kernel<FUSED, P, WV>), dim3(pipe_grid(nblk, nf, xc, K)), tb, 0, 0, in, out, geom(xc), m, pp, ws2.rec, ws2.ysum2); }
+    add("P  mark ring P=4 K=1 (= shipped schedule)", rw, RING_M(false, 4, 4, 1, 1));
+    add("P  mark ring P=4 K=4 contiguous", rw, RING_M(false, 4, 4, 4, 1));
+    add("P  mark ring P=7 K=4 contiguous", rw, RING_M(false, 7, 4, 4, 1));
+    add("P  mark ring P=7 K=4 strided", rw, RING_M(false, 7, 4, 4, 0));
+    add("P  mark ring P=7 K=8 contiguous", rw, RING_M(false, 7, 4, 8, 1));
+    add("P  mark ring P=7 K=16 contiguous", rw, RING_M(false, 7, 4, 16, 1));
+    add("PF fused ring P=4 K=4 contiguous", rw, RING_M(true, 4, 3, 4, 1));
+    add("PF fused ring P=7 K=4 contiguous", rw, RING_M(true, 7, 3, 4, 1));
+    add("PF fused ring P=7 K=4 strided", rw, RING_M(true, 7, 3, 4, 0));
+    add("PF fused ring P=7 K=8 contiguous", rw, RING_M(true, 7, 3, 8, 1));
+    add("PF fused ring P=7 K=16 contiguous", rw, RING_M(true, 7, 3, 16, 1));
+    add("PF fused ring P=7 K=2 contiguous", rw, RING_M(true, 7, 3, 2, 1));
+#define RING_A(P, WV, K, CONTIG, LDS) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((analyze_ring_kernel<P, WV>), dim3(pipe_grid(nblk, nf, xc, K)), tb, LDS, 0, in, geom(xc), pp, ws2.rec, ws2.ysum); }
+    add("PA analyze ring P=4 K=1, 3 WG/CU (= shipped)", rd, RING_A(4, 4, 1, 1, 48 * 1024));
+    add("PA analyze ring P=4 K=4 contiguous, 3 WG/CU", rd, RING_A(4, 4, 4, 1, 48 * 1024));
+    add("PA analyze ring P=7 K=4 contiguous, 3 WG/CU", rd, RING_A(7, 3, 4, 1, 48 * 1024));
+    add("PA analyze ring P=7 K=4 strided, 3 WG/CU", rd, RING_A(7, 3, 4, 0, 48 * 1024));
+    add("PA analyze ring P=7 K=8 contiguous, 3 WG/CU", rd, RING_A(7, 3, 8, 1, 48 * 1024));
+    add("PA analyze ring P=7 K=16 contiguous, 3 WG/CU", rd, RING_A(7, 3, 16, 1, 48 * 1024));
+    add("PA analyze ring P=7 K=4 contiguous, 4 WG/CU", rd, RING_A(7, 4, 4, 1, 0));
+    add("PA analyze ring P=7 K=4 contiguous, 2 WG/CU", rd, RING_A(7, 3, 4, 1, 72 * 1024));
+
+    if (pmc) {      // names in dispatch order, for tools/ladder_summary.py (the last 2 x V dispatches of the process)
+        for (auto &v : V) printf("VARIANT %s\n", v.name.c_str());
+    }
+    // ---- correctness of every variant that claims the shipped result (XCD order and linear order)
+    for (int xc : {8, 0}) {
+        if (pmc) break;
+        for (auto &v : V) {
+            const char c0 = v.name[0];
+            if (c0 == 'L' || c0 == 'B') continue;
+            if (c0 == 'A' || (c0 == 'P' && v.name[1] == 'A')) {
+                CK(hipMemset(ws2.rec, 0xff, ws.plane * kRec * 4)); CK(hipMemset(ws2.ysum, 0xff, (size_t)nf * ws.tiles * 8));
+                v.launch(xc);
+                CK(hipDeviceSynchronize());
+                const bool ok = cksum(ws2.rec, ws.plane * kRec * 4) == ref_arec && cksum(ws2.ysum, (size_t)nf * ws.tiles * 8) == ref_ays;
+                printf("# identical to the shipped kernel's result: %-46s %s\n", (v.name + (xc ? " [xcd]" : " [lin]")).c_str(), ok ? "yes" : "NO");
+                if (!ok) ++bad;
+                continue;
+            }
+            const bool fused = c0 == 'F' || (c0 == 'P' && v.name[1] == 'F');
+            if (fused) { CK(hipMemset(ws2.rec, 0xff, ws.plane * kRec * 4)); CK(hipMemset(ws2.ysum2, 0xff, (size_t)nf * ws.tiles * 8)); }
+            v.launch(xc);
+            check((v.name + (xc ? " [xcd]" : " [lin]")).c_str(), fused);
+        }
+    }
+    if (bad) { printf("# %d variants differ from the shipped kernels -- their timings mean nothing\n", bad); }
+
+    if (pmc) {
+        for (auto &v : V) { v.launch(pmc_order); v.launch(pmc_order); CK(hipDeviceSynchronize()); }
+        return bad ? 1 : 0;
+    }
+
+    // ---- pre-heat (clocks), then interleaved timing
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 300; ++i) V[0].launch(8);
+    CK(hipDeviceSynchronize());
+    for (int round = 0; round < rounds; ++round) {
+        for (auto &v : V) {
+            for (int oi = 0; oi < 2; ++oi) {
+                const int xc = oi ? 8 : 0;
+                v.launch(xc); v.launch(xc);
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < reps; ++i) v.launch(xc);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                v.ms[oi].push_back(ms / reps);
+            }
+        }
+        fprintf(stderr, "round %d done\n", round);
+    }
+    printf("# %d x 1080p, %d rounds x %d launches per figure, median of rounds (min) -- ms per launch and TB/s of the algorithmic bytes\n", nf, rounds, reps);
+    printf("%-48s %22s %22s\n", "rung", "linear order", "XCD order");
+    for (auto &v : V) {
+        printf("%-48s", v.name.c_str());
+        for (int oi = 0; oi < 2; ++oi) {
+            std::vector<double> s = v.ms[oi];
+            std::sort(s.begin(), s.end());
+            const double med = s[s.size() / 2], mn = s[0];
+            printf("   %7.4f (%6.4f) %5.2f", med, mn, v.bytes / (med * 1e-3) / 1e12);
+        }
+        printf("\n");
+    }
+    return bad ? 1 : 0;
+}

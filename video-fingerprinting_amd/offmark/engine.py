@@ -41,33 +41,19 @@ def balanced_chunk(n: int, cap: int) -> int:
 
 
 # ---- tile order of the frame-writing DCT kernel (include/offmark_hip.h: OFMK_F_LINEAR_TILES / OFMK_F_XCD_TILES) ----------------
-# DEFAULT ("auto"): no measurement.  The library itself applies a static rule on the bytes of frames a launch reads -- XCD-aware
-# order from 192 frames of 1080p per launch up, linear below -- which is what every interleaved A/B of rounds 3-4 says (large
-# launches: XCD-aware wins by 1.5-3.4 % or ties; 48-96 frames: linear wins by 1-4 %; profiles/r4_mark_fused_pass.txt).  Round 4
-# measured the order on the first large call of every exact launch shape instead: 0.25-0.8 s and ~256 repeats of the caller's
-# call per new batch length, for ~1 % of a step -- gone from the default path.
-# OPT-IN: DctEngine(tile_order="calibrate") / OFFMARK_TILE_ORDER=calibrate measures on the first large marking call of a
-# BUCKET (device, kernel, floor(log2(bytes per launch))), and DctEngine.calibrate_tile_order() measures when the caller says
-# so; records are per process, shared by all engines of that device ("auto" engines use them too), taken under a lock, and
-# the implicit form stops measuring once the process has spent OFFMARK_CALIBRATE_BUDGET_MS (default 2 000) on it.  A measured
-# order replaces the static rule's only when it wins by at least 1 % (box-to-box and placement noise is 3-5 %; a tie keeps
-# the rule and is recorded as one).  Results never depend on the order.
-_TILE_ORDER = {}              # (device index, fused, log2 bucket) -> dict(order=..., xcd_ms=..., linear_ms=..., tie=..., ...)
+# No measurement anywhere.  The library applies a static rule on the bytes of frames a launch reads -- XCD-aware order from 192
+# frames of 1080p per launch up, linear below -- which is what every interleaved A/B since round 3 says (large launches: the
+# XCD-aware order wins by 1.5-6 % or ties, depending on where the driver put the caller's frames; 48-96 frames per launch: linear
+# wins by 1-4 %; profiles/r4_mark_fused_pass.txt, profiles/r6_mark_ladder.txt).  An engine can force an order (tile_order="xcd" /
+# "linear", OFFMARK_TILE_ORDER, or the caller's own ofmk_opts flags).  Rounds 4-5 also carried an opt-in per-bucket calibration;
+# it steered an effect the driver's box measured at 0.15 % and is gone.  Results never depend on the order.
 _TILE_ORDER_LOCK = threading.RLock()
-_CALIBRATION_SPENT_MS = [0.0]
-_CALIBRATION_BUDGET_MS = float(os.environ.get("OFFMARK_CALIBRATE_BUDGET_MS", 2000))
-_CALIBRATE_MARGIN = 0.01
 _XCC_DEAL = {}                # device index -> probe_xcc_deal() result
-_CALIBRATE_MIN_BYTES = 192 << 20
 
 
 def static_tile_order(launch_bytes: int) -> str:
     """The library's rule (csrc/offmark_kernels.hip: tile_xcds), restated for reporting."""
     return "xcd" if launch_bytes >= _hip.XCD_TILES_MIN_BYTES else "linear"
-
-
-def order_bucket(launch_bytes: int) -> int:
-    return max(int(launch_bytes), 1).bit_length() - 1
 
 
 def probe_xcc_deal(device=None, workgroups: int = 4096) -> dict:
@@ -102,9 +88,8 @@ class DctEngine:
     def __init__(self, device=None, chunk_frames: int | None = None, opts=None, tile_order: str | None = None):
         """opts: an _hip.Opts applied to every batch call of this engine (flags, timing object); engines share
         no state, so two engines on two streams may be driven from two threads.
-        tile_order: "auto" (default: $OFFMARK_TILE_ORDER, else "auto" = the library's static rule on the launch size, no
-        measurement) | "xcd" | "linear" (forced) | "calibrate" (measure once per device and size bucket on the first large
-        marking call, see the module text).  A pure scheduling choice: results do not depend on it."""
+        tile_order: "auto" (default: $OFFMARK_TILE_ORDER, else "auto" = the library's static rule on the launch size) | "xcd" |
+        "linear" (forced).  A pure scheduling choice: results do not depend on it."""
         self.opts = opts
         self.torch = _hip.require_gpu()
         self.lib = _hip.load()
@@ -112,13 +97,11 @@ class DctEngine:
             else self.torch.device(device)
         self.chunk_frames = chunk_frames
         order = tile_order or os.environ.get("OFFMARK_TILE_ORDER", "auto")
-        if order not in ("auto", "xcd", "linear", "calibrate"):
-            raise ValueError(f"tile_order must be 'auto', 'xcd', 'linear' or 'calibrate', not {order!r}")
+        if order not in ("auto", "xcd", "linear"):
+            raise ValueError(f"tile_order must be 'auto', 'xcd' or 'linear', not {order!r}")
         self._order_mode = order
         self._opts_cache = None
-        self._last_key = None
         self._last_bytes = 0
-        self.calibrated_at = None
         # range-check device-resident row maps too (costs a host synchronisation per call, so off by default; the kernels
         # clamp every entry into [0, n_wm) either way -- include/offmark_hip.h)
         self.debug_checks = os.environ.get("OFFMARK_DEBUG_CHECKS", "0") not in ("", "0")
@@ -146,29 +129,19 @@ class DctEngine:
     def device_key(self):
         return self.device.index if self.device.index is not None else self.torch.cuda.current_device()
 
-    def _order_key(self, launch_bytes, fused):
-        return (self.device_key, int(bool(fused)), order_bucket(launch_bytes))
-
     @property
     def tile_order(self) -> str:
-        """The order the last marking call ran in: this engine's forced choice, else a calibration record of that call's bucket,
-        else the static rule for that call's launch size."""
+        """The order the last marking call ran in: this engine's (or its opts') forced choice, else the static rule for that
+        call's launch size."""
         if self._order_mode in ("xcd", "linear"):
             return self._order_mode
-        pinned = self._pinned()
-        if pinned:
-            return pinned
-        rec = _TILE_ORDER.get(self._last_key)
-        return rec["order"] if rec else static_tile_order(self._last_bytes)
+        return self._pinned() or static_tile_order(self._last_bytes)
 
     @property
     def tile_order_info(self) -> dict:
-        rec = _TILE_ORDER.get(self._last_key)
-        policy = ("forced" if self._order_mode in ("xcd", "linear") or self._pinned() else
-                  "calibrated" if rec else "static rule")
-        return dict(rec or {}, mode=self._order_mode, in_use=self.tile_order, policy=policy,
-                    launch_bytes=self._last_bytes, static_rule=static_tile_order(self._last_bytes),
-                    xcd_from_bytes=_hip.XCD_TILES_MIN_BYTES)
+        policy = "forced" if self._order_mode in ("xcd", "linear") or self._pinned() else "static rule"
+        return dict(mode=self._order_mode, in_use=self.tile_order, policy=policy, launch_bytes=self._last_bytes,
+                    static_rule=static_tile_order(self._last_bytes), xcd_from_bytes=_hip.XCD_TILES_MIN_BYTES)
 
     def _pinned(self):
         """The order the caller's own opts force, if any."""
@@ -182,22 +155,18 @@ class DctEngine:
 
     def _o(self, launch_bytes=None, fused=True):
         """ctypes argument for this call's ofmk_opts: the engine's opts (flags, timing) plus, for a call that runs the frame-writing
-        DCT kernel (``launch_bytes`` = bytes of frames per launch), the tile order: forced, calibrated for that bucket, or none
-        (the library's static rule)."""
+        DCT kernel (``launch_bytes`` = bytes of frames per launch), the engine's forced tile order, if it has one (else none: the
+        library's static rule)."""
         base = self.opts
         flags = base.flags if base is not None else 0
         xcds = base.xcds if base is not None else 0
         if launch_bytes is not None:
-            self._last_key, self._last_bytes = self._order_key(launch_bytes, fused), int(launch_bytes)
+            self._last_bytes = int(launch_bytes)
             if not self._pinned():
-                rec = _TILE_ORDER.get(self._last_key)
-                order = self._order_mode if self._order_mode in ("xcd", "linear") else (rec["order"] if rec else None)
-                if order == "linear":
+                if self._order_mode == "linear":
                     flags |= _hip.F_LINEAR_TILES
-                elif order == "xcd":
+                elif self._order_mode == "xcd":
                     flags |= _hip.F_XCD_TILES
-                if rec and not xcds and rec.get("xcds", 8) != 8:          # a device whose probe counted other than 8 XCDs (partition modes)
-                    xcds = rec["xcds"]
         if base is not None and flags == base.flags and xcds == base.xcds:
             return _hip.opts_ref(base)
         if flags == 0 and xcds == 0 and base is None:
@@ -206,107 +175,9 @@ class DctEngine:
         self._opts_cache = o                                  # alive until the next call
         return _hip.opts_ref(o)
 
-    def _calibrate(self, key, launch, base_flags, min_ms, max_ms, launch_bytes, chunks=1) -> dict:
-        """Core of the calibration: ``launch(opts)`` enqueues THE CALL BEING CALIBRATED (the caller's own embed / embed+detect
-        call on its own buffers) with the given ofmk_opts; it is issued in blocks of 8 (A B B A A B B A), the mark kernel's
-        launches timed by the dispatches' own timestamps (one event pool per order), the device kept busy from the first block
-        to the last.  Why the caller's whole call and not just the kernel in question: on this device every change of load
-        pattern is followed by ~10-20 ms of slower launches (power management, profiles/r4_idle_gap.txt), so the calibration must
-        BE the steady state it hands over to.  And a device coming out of idle keeps speeding up for ~100 ms of load, so blocks
-        are added until at least ``min_ms`` of sustained load have passed and a block's mean is within 0.5 % of the previous
-        one's (or ``max_ms`` have passed); the decision is taken on the last four blocks only and needs a 1 % margin to leave
-        the static rule's order."""
-        import time
-        t = self.torch
-        deal = probe_xcc_deal(self.device)
-        xcds = deal["xcds"] if deal["round_robin"] else 0
-        kinds = (1 << _hip.TIMING_KINDS.index("mark_fused")) | (1 << _hip.TIMING_KINDS.index("mark"))
-        per_block = 4 * max(1, int(chunks)) + 4               # timed launches per order and block: 4 calls x chunks per call
-        pools = {"xcd": _hip.Timing(per_block, kinds), "linear": _hip.Timing(per_block, kinds)}
-        keep = base_flags & ~(_hip.F_LINEAR_TILES | _hip.F_XCD_TILES)
-        opts = {"xcd": _hip.Opts(keep | _hip.F_XCD_TILES, xcds, pools["xcd"].handle),
-                "linear": _hip.Opts(keep | _hip.F_LINEAR_TILES, xcds, pools["linear"].handle)}
-        blocks, settled = [], False                           # per block: {order: mean launch ms}
-        t_start = time.perf_counter()
-        try:
-            while True:
-                for order in ("xcd", "linear", "linear", "xcd", "xcd", "linear", "linear", "xcd"):
-                    launch(_hip.opts_ref(opts[order]))
-                t.cuda.current_stream().synchronize()
-                got = {}
-                for k, p in pools.items():
-                    c = p.collect()
-                    ms = c["mark_fused"]["ms_total"] + c["mark"]["ms_total"]
-                    got[k] = ms / max(c["mark_fused"]["launches"] + c["mark"]["launches"], 1)
-                blocks.append(got)
-                spent = 1e3 * (time.perf_counter() - t_start)
-                if len(blocks) >= 4 and spent >= min_ms:
-                    now, before = sum(blocks[-1].values()), sum(blocks[-2].values())
-                    settled = abs(now - before) <= 0.005 * before
-                    if settled or spent >= max_ms:
-                        break
-                elif spent >= max_ms:
-                    break
-        finally:
-            for p in pools.values():
-                p.close()
-        med = {k: float(np.mean([b[k] for b in blocks[-4:]])) for k in ("xcd", "linear")}
-        default = static_tile_order(launch_bytes) if deal["round_robin"] else "linear"
-        other = "linear" if default == "xcd" else "xcd"
-        wins = deal["round_robin"] and settled and med[other] < med[default] * (1.0 - _CALIBRATE_MARGIN)
-        order = other if wins else default
-        spent_ms = 1e3 * (time.perf_counter() - t_start)
-        info = dict(order=order, tie=not wins, static_rule=default, xcd_ms=round(med["xcd"], 5), linear_ms=round(med["linear"], 5),
-                    margin=_CALIBRATE_MARGIN, blocks=len(blocks), calls_each=4 * len(blocks),
-                    first_block_ms=round(0.5 * sum(blocks[0].values()), 5), last_block_ms=round(0.5 * sum(blocks[-1].values()), 5),
-                    settled=bool(settled), calibration_ms=round(spent_ms, 1), launch_bytes=int(launch_bytes), bucket_log2=key[2],
-                    kernel="mark+verify" if key[1] else "mark", xcds=deal["xcds"], round_robin=deal["round_robin"])
-        self.calibrated_at = time.perf_counter()              # (bench.py reports the host time between this and its first warm-up launch)
-        _CALIBRATION_SPENT_MS[0] += spent_ms
-        _TILE_ORDER[key] = info
-        return info
-
     def _launch_marking(self, launch, frames, out, launch_bytes, fused, chunks=1):
-        """Issue a marking call: ``launch(opts)`` enqueues it.  Mode "calibrate" only: the first large call of a (device, kernel,
-        size bucket) is preceded by the calibration, which runs that very call (same buffers, same arguments: the results it
-        leaves are the call's own results) -- while the process's calibration budget lasts."""
-        key = self._order_key(launch_bytes, fused)
-        if (self._order_mode == "calibrate" and not self._pinned() and key not in _TILE_ORDER
-                and frames.numel() >= _CALIBRATE_MIN_BYTES and out.data_ptr() != frames.data_ptr()
-                and _CALIBRATION_SPENT_MS[0] < _CALIBRATION_BUDGET_MS
-                and not self.torch.cuda.is_current_stream_capturing()):
-            with _TILE_ORDER_LOCK:
-                if key not in _TILE_ORDER:
-                    self._calibrate(key, launch, self.opts.flags if self.opts is not None else 0, 250.0, 800.0, launch_bytes, chunks)
+        """Issue a marking call: ``launch(opts)`` enqueues it with this call's ofmk_opts."""
         launch(self._o(launch_bytes, fused))
-
-    def calibrate_tile_order(self, frames, out=None, min_ms: float = 250.0, max_ms: float = 800.0, force: bool = False) -> dict:
-        """Explicit calibration of the fused mark+verify call on ``frames`` (CUDA uint8 [n, H, W, 3]) with a test watermark,
-        for callers that want it done at a moment of their choosing (see _calibrate).  Synchronises; ``out`` (default: a
-        temporary buffer) must not alias ``frames``.  Returns the calibration record of this device and size bucket, which every
-        engine of this device then uses for launches of that bucket."""
-        t = self.torch
-        n, H, W = self._check_frames(frames, t.uint8)
-        cf = self._chunk(n, H, W)
-        fused = not (self.opts is not None and self.opts.flags & _hip.F_SEPARATE_DETECT)
-        launch_bytes = cf * H * W * 3
-        key = self._order_key(launch_bytes, fused)
-        self._last_key, self._last_bytes = key, launch_bytes
-        with _TILE_ORDER_LOCK:
-            if key in _TILE_ORDER and not force:
-                return _TILE_ORDER[key]
-            dst = t.empty_like(frames) if out is None or out.data_ptr() == frames.data_ptr() else self._out(out, frames)
-            wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=self.device)
-            wm[0, ::2] = 1
-            counts = t.empty((n, 8), dtype=t.int32, device=self.device)
-            ws = self.workspace(H, W, cf)
-            stream = _hip.current_stream()
-
-            def launch(o):
-                _hip.check(self.lib.ofmk_embed_detect_rgb8(frames.data_ptr(), dst.data_ptr(), n, H, W, wm.data_ptr(), 1, None, 20.0, 8,
-                                                           counts.data_ptr(), None, cf, ws.data_ptr(), ws.numel(), stream, o))
-            return self._calibrate(key, launch, self.opts.flags if self.opts is not None else 0, min_ms, max_ms, launch_bytes,
-                                   chunks=-(-n // cf))
 
     def _check_frames(self, frames, dtype):
         t = self.torch
