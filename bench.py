@@ -262,7 +262,7 @@ def oracle_check(frames_u8, marked_u8, gpu_bits_of_oracle_marked, wm_rows, alpha
         ref_marked[i] = c_oracle.mark_frames(frames_u8[i:i + 1], wm, alpha=alpha, legacy=True, threads=1)[0][0]
         ref_bits.append(c_oracle.check_frames(ref_marked[i:i + 1], alpha=alpha, legacy=True, threads=1)[0][0])
         enc = orc.DctEncoderOracle(alpha=alpha)
-        enc.read_wm(wm)
+        enc.read_wm(np.asarray(wm).reshape(1, -1))            # read_wm keeps wm[0], like the reference (dct_encoder.py:10-11)
         enc.encode(orc.bgr2yuv_f32(frames_u8[i].astype(np.float32)))
         ok = np.abs(enc.debug["c21_pre"]) > 1e-3
         amb += int((~ok).sum())
@@ -711,13 +711,13 @@ def main():
                 if a.codec == "dct":
                     counts, _ = e.detect(j.frames, L, alpha=a.alpha)
                 else:
-                    counts, _ = e.svd_detect(j.frames, L, scale=15, blk=a.blk)
+                    counts, _ = e.svd_detect(j.frames, L, scale=15, blk=a.blk, partial=True)       # per-workgroup sums: no fill dispatch
             elif planar:
                 _, counts, _ = e.embed_detect_yuv420(j.planes, H, W, j.wm_dev, L, alpha=a.alpha, out=out, layout=a.pixfmt)
             elif a.codec == "dct":
                 _, counts, _ = e.embed_detect(j.frames, j.wm_dev, L=L, alpha=a.alpha, wm_row=j.rows_dev, out=out)
             else:
-                _, counts, _ = e.svd_embed_detect(j.frames, j.wm_dev, L=L, scale=15, wm_row=j.rows_dev, out=out, blk=a.blk)
+                _, counts, _ = e.svd_embed_detect(j.frames, j.wm_dev, L=L, scale=15, wm_row=j.rows_dev, out=out, blk=a.blk, partial=True)
             e.payloads(counts, n_bits, perm_dev, out=slot)
 
         def hot_path(self, lane):
@@ -963,7 +963,7 @@ def main():
 
     if cfg == 5 and world == 1 and not a.no_extras and n and not emu:
         e0 = lanes[0].eng
-        det = (lambda x: e0.detect(x, L, alpha=a.alpha)[0]) if a.codec == "dct" else (lambda x: e0.svd_detect(x, L, scale=15, blk=a.blk)[0])
+        det = (lambda x: e0.detect(x, L, alpha=a.alpha)[0]) if a.codec == "dct" else (lambda x: e0.svd_detect(x, L, scale=15, blk=a.blk)[0])      # plain [n, L] counts
         extra["attacks"] = attack_suite(torch, det, job.leak_sample, job.keep, [job.expected[s] for s in range(S)], job.chosen, fp,
                                         vote_segments, deg, n_bits, H, W, "DCT" if a.codec == "dct" else f"DwtDctSvd(blk={a.blk})")
     # the same K steps once more, straight after the timed region.  `value` is the contract's figure (W warm-up steps after
@@ -1133,7 +1133,7 @@ def main():
         k4 = max(3, min(a.steps, 20))
         for blk, key in ((4, "dwtdctsvd"), (8, "dwtdctsvd_blk8")):
             def svd_step(blk=blk):
-                _, c, _ = e0.svd_embed_detect(job.frames, job.wm_dev, L=L, scale=15, wm_row=job.rows_dev, out=lanes[0].out, blk=blk)
+                _, c, _ = e0.svd_embed_detect(job.frames, job.wm_dev, L=L, scale=15, wm_row=job.rows_dev, out=lanes[0].out, blk=blk, partial=True)
                 return e0.payloads(c, DctEngine.svd_bits_per_frame(H, W, blk), perm_dev)
             el4, pm = side_rate(svd_step, k4)
             extra[key] = dict(value=round(world * n * k4 / el4, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el4 / k4, 4),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define OFMK_ABI_VERSION 5
+#define OFMK_ABI_VERSION 6
 
 #define OFMK_OK            0
 #define OFMK_E_ARG        -1   /* null pointer / non-positive size / H or W < 8 */
@@ -71,6 +71,13 @@ typedef struct ofmk_opts {
 #define OFMK_F_LINEAR_TILES 2u
 #define OFMK_F_XCD_TILES 4u
 #define OFMK_XCD_TILES_MIN_BYTES 1194393600ull      /* 192 x 1080 x 1920 x 3 */
+/* DwtDctSvd read-outs (ofmk_svd_detect_rgb8, ofmk_svd_embed_detect_rgb8) only: `counts` is the PARTIAL form, device int32
+ * [n][tiles][L] with tiles = ofmk_svd_count_tiles(H, W, blk) -- every workgroup of the frame kernel STORES the L sums of its own
+ * tile, so the launch clears nothing first (no fill dispatch, no global atomics) and the buffer may hold anything before the
+ * call.  ofmk_payloads_from_partial_counts adds the tiles up and runs DeShuffler.degenerate's epilogue
+ * (de_shuffler.py:17-22; dwt_dct_svd_decoder.py:12-37 produced the bits).  L <= 2048 (else OFMK_E_ARG: use plain counts);
+ * any other entry point rejects the flag's meaning by ignoring it. */
+#define OFMK_F_PARTIAL_COUNTS 8u
 /* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
  * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to
  * what fits.  Bigger chunks are faster (fewer launches, shorter tails): keeping a chunk resident
@@ -191,6 +198,13 @@ int ofmk_rgb8_to_yuv420(const uint8_t *rgb, uint8_t *yuv, int layout, int n, int
  * mid-range of the L means.  payload: device u8 [n][L].  n_bits = H*W/64.                   */
 int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, const int32_t *perm,
                               uint8_t *payload, void *stream, const ofmk_opts *opts);
+/* Rows of a frame's partial counts (OFMK_F_PARTIAL_COUNTS) for the DwtDctSvd codec with this blk; negative on bad arguments. */
+int ofmk_svd_count_tiles(int H, int W, int blk);
+/* The payload epilogue from partial counts [n][tiles][L] (OFMK_F_PARTIAL_COUNTS): per frame, counts[i] = sum over tiles, then
+ * exactly ofmk_payloads_from_counts (de_shuffler.py:17-22).  payload: device u8 [n][L] or NULL; counts: device int32 [n][L]
+ * or NULL (the summed counts, for callers that want DeShuffler's numerators); at least one of the two.  L <= 2048. */
+int ofmk_payloads_from_partial_counts(const int32_t *partials, int tiles, int n, int L, int n_bits, const int32_t *perm,
+                                      uint8_t *payload, int32_t *counts, void *stream, const ofmk_opts *opts);
 
 /* ---- plugin-level entry points on float32 YUV frames --------------------------------------
  * DctEncoder.encode(yuv) (dct_encoder.py:18-39; mutates channel 1 in place) and

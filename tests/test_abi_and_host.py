@@ -36,7 +36,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
                 and ("ofmk" in l or " g_" in l) and "(" not in l          # "name(args)" = a kernel's launch handle
                 and "g_err" not in l and "guard variable" not in l]
     assert not writable, writable
-    assert lib.ofmk_version() == _hip.ABI_VERSION == 5
+    assert lib.ofmk_version() == _hip.ABI_VERSION == 6
     # pure host-side entry points are safe to call without a GPU
     assert lib.ofmk_workspace_bytes(1, 1080, 1920) == 32400 * 4 * 4 + 2 * 127 * 8 + 4096      # records + delta, 2 x 127 per-tile partial sums
     assert lib.ofmk_workspace_bytes(0, 1080, 1920) == 0 and lib.ofmk_workspace_bytes(1, 4, 1920) == 0
@@ -414,7 +414,6 @@ def test_chunk_choice_never_exceeds_what_the_library_launches():
     header = open(os.path.join(ROOT, "include", "offmark_hip.h")).read()
     assert f"#define OFMK_XCD_TILES_MIN_BYTES {_hip.XCD_TILES_MIN_BYTES}ull" in header
     assert E.static_tile_order(_hip.XCD_TILES_MIN_BYTES) == "xcd" and E.static_tile_order(_hip.XCD_TILES_MIN_BYTES - 1) == "linear"
-    assert E.order_bucket(48 * 1080 * 1920 * 3) == E.order_bucket(60 * 1080 * 1920 * 3) == 28 and E.order_bucket(40 * 1080 * 1920 * 3) == 27
-    assert (_hip.F_SEPARATE_DETECT, _hip.F_LINEAR_TILES, _hip.F_XCD_TILES) == (1, 2, 4)
-    for name, value in (("OFMK_F_SEPARATE_DETECT", 1), ("OFMK_F_LINEAR_TILES", 2), ("OFMK_F_XCD_TILES", 4)):
+    assert (_hip.F_SEPARATE_DETECT, _hip.F_LINEAR_TILES, _hip.F_XCD_TILES, _hip.F_PARTIAL_COUNTS) == (1, 2, 4, 8)
+    for name, value in (("OFMK_F_SEPARATE_DETECT", 1), ("OFMK_F_LINEAR_TILES", 2), ("OFMK_F_XCD_TILES", 4), ("OFMK_F_PARTIAL_COUNTS", 8)):
         assert f"#define {name} {value}u" in header

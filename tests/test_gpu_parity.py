@@ -1158,6 +1158,35 @@ def test_bench_configs_run_at_one_gpu(config, extra):
         assert line["pcie_inclusive"]["i420"]["frames_per_s"] > 0 and line["pcie_inclusive"]["rgb24"]["frames_per_s"] > 0
 
 
+@pytest.mark.parametrize("config,size", [(2, ["--height", "360", "--width", "640", "--frames", "12"]), (4, ["--height", "240", "--width", "320", "--frames", "6"])])
+def test_bench_line_checks_its_own_timed_frames_against_the_oracle(config, size):
+    """the line itself compares frames of the TIMED batch and the marked frames the timed steps wrote with
+    the C oracle's embed + detect (beside the CPU baseline): `oracle_check` with the parity tests' budgets, and a budget overrun
+    turns payload_bit_exact false.  Also in every default line now: the non-fused mark kernel's own figures (`kernels.mark`),
+    the contract read from idle (`value_no_preheat`) and CPU baseline variant A over ten frames.  dct_decoder.py:10-27."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", str(config), "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "1", *size], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    oc = line["oracle_check"]
+    assert "error" not in oc, oc
+    assert oc["within_budget"] and oc["payload_equal"] and line["payload_bit_exact"]
+    assert oc["frames"] == len(oc["frame_indices"]) >= 2 and oc["max_pixel_difference"] <= 1 and oc["raw_bits_differing"] <= 1
+    assert oc["pixels_compared"] > 0 and oc["pixels_differing_over_determined_blocks"] <= max(1, oc["pixels_compared"] // 100000)
+    assert line["value_no_preheat"] > 0 and line["no_preheat"]["votes_ok"] and line["config"]["preheat_ms"] > 0
+    if config == 2:
+        k = line["kernels"]["mark"]
+        assert k["launches"] >= 3 and k["avg_launch_ms"] > 0 and 0 < k["frac_of_peak"] < 1 and k["achieved_GBps"] > 0
+        a_ = line["cpu_baseline"]["variants"]["A_reference_shaped_loop"]
+        assert a_["frames"] == 10 and a_["payload_ok"] and a_["value"] > 0 and a_["cores"] == 1
+    print("oracle_check:", {k_: v for k_, v in oc.items() if k_ != "note"})
+
+
 def test_bench_config3_4k_at_its_stated_size():
     """BASELINE.json configs[2] (4K, HBM-bound stress) AT ITS STATED SIZE: 1000 frames of 3840x2160 per step = 24.9 GB in +
     24.9 GB out, three equal internal chunks (334 frames) under the default 8 GiB cap.  Payloads exact; the path must hold
@@ -1244,9 +1273,9 @@ def test_bench_two_ranks_gloo_on_one_device(config, launcher):
     # what every rank measured by itself: three figures per rank, and how far the slowest is from the median
     pr, sc = line["per_rank"], line["scaling_efficiency_inputs"]
     assert len(pr["ms_per_step"]) == len(pr["dominant_kernel_ms"]) == len(pr["analyze_ms"]) == 2
-    assert all(x is not None and x > 0 for x in pr["ms_per_step"]) and max(pr["ms_per_step"]) <= line["ms_per_step"] * 1.0001
+    assert all(x is not None and x > 0 for x in pr["ms_per_step"]) and max(pr["ms_per_step"]) <= line["ms_per_step"] + 1e-4       # (the line rounds to 4 decimals)
     assert all(x is not None and x > 0 for x in pr["analyze_ms"]) and pr["dominant_kernel"] == "mark_fused"
-    assert sc["slowest_rank"] in (0, 1) and sc["slowest_over_median"] >= 1.0 and sc["slowest_ms_per_step"] == max(pr["ms_per_step"])
+    assert sc["slowest_rank"] in (0, 1) and sc["slowest_over_median"] >= 1.0 and abs(sc["slowest_ms_per_step"] - max(pr["ms_per_step"])) < 1e-9
     assert line["config"]["frames_per_gpu"] == (8 if config == 2 else 4 * 8)      # config 4: 8 segments / 2 ranks x 8 frames
     assert line["config"]["steps_per_host_iteration"] == 3 and line["config"]["hipgraph"]   # small shards: the three steps are ONE graph, gathered and voted on together
     assert line["host_ms_per_step"]["over"] == "max over ranks" and "placement" in line

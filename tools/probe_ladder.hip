@@ -639,7 +639,8 @@ int main(int argc, char **argv) {
     add("L4   same chain, 8 rows stored at the end", rw, RUNG(4, 20, 4));
     add("L3'+ 36 fma/px chain, row-by-row (3 waves)", rw, RUNG(3, 36, 3));
     add("L4'  same chain, stores at the end (3 waves)", rw, RUNG(4, 36, 3));
-    add("R  real mark (non-fused), shipped", rw, [&](int xc) { hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
+    add("R  real mark (non-fused), row-by-row stores", rw, [&](int xc) { hipLaunchKernelGGL((mark_rgb8_kernel<true, false>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
+    add("RH real mark (non-fused), HOLD (product kernel)", rw, [&](int xc) { hipLaunchKernelGGL((mark_rgb8_kernel<true, false, true>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
     add("R1 real mark, FrameLum precomputed", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<1, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
     add("R2 real mark, stores at the end", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<2, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
     add("R3 real mark, both", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<3, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });

@@ -193,7 +193,7 @@ int carve(void *ws, size_t bytes, int H, int W, int want_frames, Workspace &out)
 
 // every entry point that takes ofmk_opts: unknown flag bits or a non-zero reserved word are a caller bug, not a default
 int check_opts(const ofmk_opts *o) {
-    if (o && ((o->flags & ~(uint32_t)(OFMK_F_SEPARATE_DETECT | OFMK_F_LINEAR_TILES | OFMK_F_XCD_TILES)) || o->xcds > 64u))
+    if (o && ((o->flags & ~(uint32_t)(OFMK_F_SEPARATE_DETECT | OFMK_F_LINEAR_TILES | OFMK_F_XCD_TILES | OFMK_F_PARTIAL_COUNTS)) || o->xcds > 64u))
         return fail(OFMK_E_ARG, "ofmk_opts: unknown flag bits or xcds > 64%s");
     if (o && (o->flags & OFMK_F_LINEAR_TILES) && (o->flags & OFMK_F_XCD_TILES))
         return fail(OFMK_E_ARG, "ofmk_opts: OFMK_F_LINEAR_TILES and OFMK_F_XCD_TILES exclude each other%s");
@@ -307,6 +307,9 @@ int launch_mark_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, const
         if (fused) {
             if (al) OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<true, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
             else OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<false, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
+        } else if (xc > 1) {      // XCD-aware order: the marked rows are stored back to back at the end (dct_kernels.hiph: mark_rows HOLD; -2.5 %)
+            if (al) OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<true, false, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
+            else OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<false, false, true>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
         } else {
             if (al) OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<true, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
             else OFMK_TIMED_LAUNCH(timing, (mark_rgb8_kernel<false, false>), grid, dim3(kThreads), 0, s, in, out, g, m, ws.rec, ws.ysum2);
@@ -396,14 +399,16 @@ int launch_svd_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mo
     none.plane = 0;
     const Geom g = make_geom(H, W, none);
     const bool al = aligned_rows(in, W, 1) && (mode == SVD_DETECT || aligned_rows(out, W, 1));
-    if (a.counts) HIP_TRY(launch_zero(a.counts, (size_t)n * a.L * sizeof(int32_t), s));
+    const size_t tiles = (size_t)(g.nblk + kThreads - 1) / kThreads;
+    // partial counts: every workgroup stores its own row, nothing to clear (OFMK_F_PARTIAL_COUNTS); else the frames' [L] sums are added into
+    if (a.counts && !a.partial) HIP_TRY(launch_zero(a.counts, (size_t)n * a.L * sizeof(int32_t), s));
     if (a.bits && a.N > g.nblk) HIP_TRY(launch_zero(a.bits, (size_t)n * a.N, s));   // entries past (H/8)(W/8) stay 0
     for (int f0 = 0; f0 < n; f0 += kMaxChunk) {
         const int cf = n - f0 < kMaxChunk ? n - f0 : kMaxChunk;
         const size_t fo = (size_t)f0 * g.frame_stride;
         SvdArgs b = a;
         if (b.wm_row) b.wm_row += f0;
-        if (b.counts) b.counts += (size_t)f0 * a.L;
+        if (b.counts) b.counts += (size_t)f0 * a.L * (a.partial ? tiles : 1);
         if (b.bits) b.bits += (size_t)f0 * a.N;
         Geom gc = g;
         gc.frames = cf;
@@ -441,7 +446,8 @@ Geom8 make_geom8(int H, int W) {
 int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int mode, Svd8Args a, const Ctx &cx) {
     hipStream_t s = cx.s;
     const Geom8 g = make_geom8(H, W);
-    if (a.counts) HIP_TRY(launch_zero(a.counts, (size_t)n * a.L * sizeof(int32_t), s));
+    const size_t tiles = (size_t)(g.ntile + kThreads - 1) / kThreads;
+    if (a.counts && !a.partial) HIP_TRY(launch_zero(a.counts, (size_t)n * a.L * sizeof(int32_t), s));
     if (a.bits && a.N8 > g.ntile) HIP_TRY(launch_zero(a.bits, (size_t)n * a.N8, s));    // entries past the tiles stay 0
     const int Hc = (((H / 4) * 2) / 8) * 16, Wc = g.wt * 16;                                    // the region the tiles cover
     if (g.ntile > 0) {
@@ -451,7 +457,7 @@ int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int m
             const size_t fo = (size_t)f0 * g.frame_stride;
             Svd8Args b = a;
             if (b.wm_row) b.wm_row += f0;
-            if (b.counts) b.counts += (size_t)f0 * a.L;
+            if (b.counts) b.counts += (size_t)f0 * a.L * (a.partial ? tiles : 1);
             if (b.bits) b.bits += (size_t)f0 * a.N8;
             Geom8 gc = g;
             gc.frames = cf;
@@ -475,6 +481,20 @@ int launch_svd8_rgb8(const uint8_t *in, uint8_t *out, int n, int H, int W, int m
     return OFMK_OK;
 }
 
+// workgroups per frame of the DwtDctSvd frame kernels = rows of a frame's partial counts (OFMK_F_PARTIAL_COUNTS)
+int svd_count_tiles(int H, int W, int blk) {
+    const long long units = blk == 8 ? (long long)make_geom8(H, W).ntile : (long long)(H / 8) * (W / 8);
+    return (int)((units + kThreads - 1) / kThreads);
+}
+
+// OFMK_F_PARTIAL_COUNTS on a DwtDctSvd read-out: the workgroup's sums live in its LDS histogram, so L is bounded by it
+int check_partial(const ofmk_opts *o, int L, const int32_t *counts, int &partial) {
+    partial = (o && (o->flags & OFMK_F_PARTIAL_COUNTS)) ? 1 : 0;
+    if (partial && !counts) return fail(OFMK_E_ARG, "OFMK_F_PARTIAL_COUNTS without a counts buffer%s");
+    if (partial && L > kHistMax) return fail(OFMK_E_ARG, "OFMK_F_PARTIAL_COUNTS needs L <= 2048 (longer payloads: plain counts)%s");
+    return OFMK_OK;
+}
+
 int check_blk(int blk) {
     if (blk != 4 && blk != 8)
         return fail(OFMK_E_ARG, "blk must be 4 (the reference's default) or 8%s");
@@ -484,7 +504,7 @@ int check_blk(int blk) {
 Svd8Args to_args8(const SvdArgs &a, int H, int W) {
     Svd8Args b;
     memset(&b, 0, sizeof(b));
-    b.wm = a.wm; b.wm_row = a.wm_row; b.n_wm = a.n_wm; b.counts = a.counts; b.bits = a.bits;
+    b.wm = a.wm; b.wm_row = a.wm_row; b.n_wm = a.n_wm; b.counts = a.counts; b.bits = a.bits; b.partial = a.partial;
     b.N = a.N; b.N8 = (int)((long long)H * W / 256); b.L = a.L;
     for (int k = 0; k < 3; ++k) b.scales[k] = a.scales[k];
     return b;
@@ -775,11 +795,12 @@ int ofmk_svd_detect_rgb8(const uint8_t *in, int n, int H, int W, int L, const do
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, true))) return rc;
+    if ((rc = check_partial(opts, L, counts, a.partial))) return rc;
     a.counts = counts; a.bits = bits; a.N = (int)((long long)H * W / 64); a.L = L;
     const size_t bits_per_frame = blk == 8 ? (size_t)((long long)H * W / 256) : (size_t)a.N;     // dwt_dct_svd_decoder.py:14
     if (!(a.scales[1] > 0.f)) {
         hipStream_t s = static_cast<hipStream_t>(stream);
-        if (counts) HIP_TRY(launch_zero(counts, (size_t)n * L * sizeof(int32_t), s));
+        if (counts) HIP_TRY(launch_zero(counts, (size_t)n * L * sizeof(int32_t) * (a.partial ? (size_t)svd_count_tiles(H, W, blk) : 1), s));
         if (bits) HIP_TRY(launch_zero(bits, (size_t)n * bits_per_frame, s));
         return OFMK_OK;
     }
@@ -798,6 +819,7 @@ int ofmk_svd_embed_detect_rgb8(const uint8_t *in, uint8_t *out, int n, int H, in
     SvdArgs a;
     memset(&a, 0, sizeof(a));
     if ((rc = set_scales(a, scales, false))) return rc;
+    if ((rc = check_partial(opts, L, counts, a.partial))) return rc;
     a.wm = wm; a.wm_row = wm_row; a.n_wm = n_wm; a.counts = counts; a.bits = bits;
     a.N = (int)((long long)H * W / 64); a.L = L;
     if (blk == 8) return launch_svd8_rgb8(in, out, n, H, W, SVD_EMBED_VERIFY, to_args8(a, H, W), make_ctx(stream, opts));
@@ -877,6 +899,24 @@ int ofmk_payloads_from_counts(const int32_t *counts, int n, int L, int n_bits, c
     if (!counts || !perm || !payload) return fail(OFMK_E_ARG, "null pointer%s");
     if (n < 1 || L < 1 || n_bits < 0) return fail(OFMK_E_ARG, "bad sizes%s");
     return launch_payloads(counts, n, L, n_bits, perm, payload, static_cast<hipStream_t>(stream));
+}
+
+int ofmk_svd_count_tiles(int H, int W, int blk) {
+    if (H < 8 || W < 8 || check_blk(blk)) return -1;
+    return svd_count_tiles(H, W, blk);
+}
+
+int ofmk_payloads_from_partial_counts(const int32_t *partials, int tiles, int n, int L, int n_bits, const int32_t *perm,
+                                      uint8_t *payload, int32_t *counts, void *stream, const ofmk_opts *opts) {
+    if (int orc = check_opts(opts)) return orc;
+    if (!partials || (!payload && !counts) || (payload && !perm)) return fail(OFMK_E_ARG, "null pointer%s");
+    if (n < 1 || L < 1 || n_bits < 0 || tiles < 0) return fail(OFMK_E_ARG, "bad sizes%s");
+    if (L > kHistMax) return fail(OFMK_E_ARG, "partial counts need L <= 2048%s");
+    if ((long long)tiles * L >= (1LL << 31)) return fail(OFMK_E_ARG, "tiles * L too large%s");
+    hipLaunchKernelGGL(degenerate_partial_kernel, dim3((unsigned)n), dim3(kThreads), 0, static_cast<hipStream_t>(stream), partials, tiles, L,
+                       n_bits, perm, payload, counts);
+    HIP_TRY(hipGetLastError());
+    return OFMK_OK;
 }
 
 // ---- planar YUV 4:2:0 entry points ------------------------------------------------------

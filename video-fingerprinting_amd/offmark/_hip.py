@@ -12,7 +12,7 @@ import os
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "liboffmark_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Opts(C.Structure):
@@ -26,6 +26,7 @@ class Opts(C.Structure):
 F_SEPARATE_DETECT = 1
 F_LINEAR_TILES = 2          # tile order of the frame-writing DCT kernel: force workgroup index order ...
 F_XCD_TILES = 4             # ... or the XCD-aware order; neither: the library's static rule on the launch size (offmark_hip.h)
+F_PARTIAL_COUNTS = 8        # DwtDctSvd read-outs: counts = per-workgroup partial sums [n][tiles][L], stored not added (no fill dispatch)
 XCD_TILES_MIN_BYTES = 192 * 1080 * 1920 * 3
 YUV_I420, YUV_NV12 = 0, 1
 TIMING_KINDS = ("analyze", "finalize", "mark", "mark_fused", "svd", "planar_analyze", "planar_mark")
@@ -55,6 +56,8 @@ SIGNATURES = {
     "ofmk_svd_encode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _dp, _i32, _vp, _op]),
     "ofmk_svd_decode_yuv32f": (_i32, [_vp, _i32, _i32, _i32, _dp, _i32, _vp, _vp, _op]),
     "ofmk_payloads_from_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _op]),
+    "ofmk_svd_count_tiles": (_i32, [_i32, _i32, _i32]),
+    "ofmk_payloads_from_partial_counts": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _op]),
     "ofmk_embed_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _sz, _vp, _op]),
     "ofmk_detect_yuv420": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _sz, _vp, _op]),
     "ofmk_embed_detect_yuv420": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _f64, _i32, _vp, _vp, _i32, _vp,

@@ -153,12 +153,12 @@ class DctEngine:
             return "xcd"
         return None
 
-    def _o(self, launch_bytes=None, fused=True):
+    def _o(self, launch_bytes=None, fused=True, extra_flags=0):
         """ctypes argument for this call's ofmk_opts: the engine's opts (flags, timing) plus, for a call that runs the frame-writing
         DCT kernel (``launch_bytes`` = bytes of frames per launch), the engine's forced tile order, if it has one (else none: the
-        library's static rule)."""
+        library's static rule); ``extra_flags``: flags of this one call (OFMK_F_PARTIAL_COUNTS)."""
         base = self.opts
-        flags = base.flags if base is not None else 0
+        flags = (base.flags if base is not None else 0) | extra_flags
         xcds = base.xcds if base is not None else 0
         if launch_bytes is not None:
             self._last_bytes = int(launch_bytes)
@@ -312,16 +312,35 @@ class DctEngine:
         self._launch_marking(launch, frames, out, min(cf, n) * H * W * 3, fused, chunks=-(-n // cf))
         return out, counts, bits
 
-    def payloads(self, counts, n_bits: int, perm, out=None):
-        """Device epilogue of DeShuffler.degenerate for a batch: counts int32 [n, L] -> uint8 [n, L]."""
+    def payloads(self, counts, n_bits: int, perm, out=None, counts_out=None):
+        """Device epilogue of DeShuffler.degenerate for a batch: counts int32 [n, L] -> uint8 [n, L].  ``counts`` may also be
+        the PARTIAL form int32 [n, tiles, L] a DwtDctSvd read-out left with ``partial=True`` (every frame-kernel workgroup's own
+        sums, stored not added): the tiles are added up inside the same kernel, and ``counts_out`` (int32 [n, L], optional)
+        receives the sums."""
         t = self.torch
-        n, L = counts.shape
         if not isinstance(perm, t.Tensor):
             perm = t.as_tensor(np.asarray(perm), dtype=t.int32).to(self.device)
+        if counts.dim() == 3:
+            n, tiles, L = counts.shape
+            if out is None:
+                out = t.empty((n, L), dtype=t.uint8, device=self.device)
+            _hip.check(self.lib.ofmk_payloads_from_partial_counts(counts.data_ptr(), tiles, n, L, int(n_bits), perm.data_ptr(), out.data_ptr(),
+                                                                  _hip.ptr(counts_out), _hip.current_stream(), self._o()))
+            return out
+        n, L = counts.shape
         if out is None:
             out = t.empty((n, L), dtype=t.uint8, device=self.device)
         _hip.check(self.lib.ofmk_payloads_from_counts(counts.data_ptr(), n, L, int(n_bits), perm.data_ptr(),
                                                       out.data_ptr(), _hip.current_stream(), self._o()))
+        return out
+
+    def counts_from_partial(self, partials, out=None):
+        """The frames' [n, L] counts from partial counts [n, tiles, L] (one small kernel; integer sums)."""
+        t = self.torch
+        n, tiles, L = partials.shape
+        out = self._counts(out, n, L)
+        _hip.check(self.lib.ofmk_payloads_from_partial_counts(partials.data_ptr(), tiles, n, L, 0, None, None, out.data_ptr(),
+                                                              _hip.current_stream(), self._o()))
         return out
 
     # -- planar 8-bit YUV 4:2:0 in and out (SURVEY 8f-3: what a decoder hands over / an encoder takes) -----------
@@ -439,27 +458,45 @@ class DctEngine:
                                                 self._o()))
         return out
 
-    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None, blk=4, counts=None):
+    def _svd_counts(self, counts, n, H, W, L, blk, partial):
+        """The read-out's counts buffer: [n, L] (cleared by the library, added into with atomics) or, ``partial``, the
+        per-workgroup form [n, tiles, L] the frame kernel stores in full -- no fill dispatch in front of it
+        (include/offmark_hip.h: OFMK_F_PARTIAL_COUNTS; L <= 2048); hand it to payloads() / counts_from_partial()."""
+        if not partial:
+            return self._counts(counts, n, L), 0
+        t = self.torch
+        tiles = int(self.lib.ofmk_svd_count_tiles(H, W, int(blk)))
+        if tiles < 0:
+            raise _hip.HipError(f"bad frame size or blk ({H}x{W}, blk={blk})")
+        if counts is None:
+            counts = t.empty((n, tiles, L), dtype=t.int32, device=self.device)
+        elif not (isinstance(counts, t.Tensor) and counts.is_cuda and counts.dtype == t.int32 and tuple(counts.shape) == (n, tiles, L)
+                  and counts.is_contiguous()):
+            raise ValueError(f"partial counts must be a contiguous CUDA int32 tensor [{n}, {tiles}, {L}]")
+        return counts, _hip.F_PARTIAL_COUNTS
+
+    def svd_detect(self, frames, L, scale=15, want_bits=False, scales=None, blk=4, counts=None, partial=False):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
-        counts = self._counts(counts, n, L)
+        counts, flag = self._svd_counts(counts, n, H, W, L, blk, partial)
         bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_detect_rgb8(frames.data_ptr(), n, H, W, int(L), _hip.scales3(scale, scales), int(blk), counts.data_ptr(),
-                                                 _hip.ptr(bits), _hip.current_stream(), self._o()))
+                                                 _hip.ptr(bits), _hip.current_stream(), self._o(extra_flags=flag)))
         return counts, bits
 
-    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None, blk=4, counts=None):
+    def svd_embed_detect(self, frames, wm, L, scale=15, wm_row=None, out=None, want_bits=False, scales=None, blk=4, counts=None,
+                         partial=False):
         t = self.torch
         n, H, W = self._check_frames(frames, t.uint8)
         wm = self._wm(wm, H * W // 64)
         rows = self._rows(wm_row, n, wm.shape[0])
         out = self._out(out, frames)
-        counts = self._counts(counts, n, L)
+        counts, flag = self._svd_counts(counts, n, H, W, L, blk, partial)
         bits = t.empty((n, self.svd_bits_per_frame(H, W, blk)), dtype=t.uint8, device=self.device) if want_bits else None
         _hip.check(self.lib.ofmk_svd_embed_detect_rgb8(frames.data_ptr(), out.data_ptr(), n, H, W, wm.data_ptr(),
                                                        wm.shape[0], _hip.ptr(rows), _hip.scales3(scale, scales), int(blk), int(L),
                                                        counts.data_ptr(), _hip.ptr(bits), _hip.current_stream(),
-                                                       self._o()))
+                                                       self._o(extra_flags=flag)))
         return out, counts, bits
 
     def svd_encode_yuv(self, yuv, wm, scale=15, scales=None, blk=4):
