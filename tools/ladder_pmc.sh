@@ -16,7 +16,6 @@ for ORDER in 8 0; do
   timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/o${ORDER}_sq -o pmc -- $P > $OUT/o${ORDER}_sq.log 2>&1 || echo "pass sq order $ORDER failed"
   timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/o${ORDER}_tcc -o pmc -- $P > $OUT/o${ORDER}_tcc.log 2>&1 || echo "pass tcc order $ORDER failed"
   timeout -k 10 300 rocprofv3 --pmc TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_32B_sum TCC_TAG_STALL_sum SQ_INSTS_VMEM_WR --output-format csv -d $OUT/o${ORDER}_stall -o pmc -- $P > $OUT/o${ORDER}_stall.log 2>&1 || echo "pass stall order $ORDER failed"
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE SQ_WAIT_ANY SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/o${ORDER}_size -o pmc -- $P > $OUT/o${ORDER}_size.log 2>&1 || echo "pass size order $ORDER failed"
 done
 cd $ROOT
 python3 tools/ladder_summary.py $OUT > $OUT/summary.txt 2> $OUT/summary.err || echo "summary failed"

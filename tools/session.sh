@@ -39,6 +39,8 @@ for step in "$@"; do
     profsvd)   run 900 profsvd bash tools/prof.sh ${TAG}svd --codec dwtdctsvd ;;
     profsvd8)  run 900 profsvd8 bash tools/prof.sh ${TAG}svd8 --codec dwtdctsvd --blk 8 ;;
     profplanar) run 900 profplanar bash tools/prof.sh ${TAG}planar --pixfmt i420 ;;
+    profembed) run 900 profembed bash tools/prof.sh ${TAG}embed --separate-detect ;;      # the NON-fused mark kernel (what tests/mark.py's operation runs) in the trace and the counters
+    ladder)    run 1100 ladder bash tools/ladder_pmc.sh ${TAG} ;;
     *) echo "unknown step $step" ;;
   esac
 done
