@@ -63,9 +63,9 @@ typedef struct ofmk_opts {
  * + L / xcds); linear order: tile = workgroup index.  A pure permutation of the work: results are identical bit for bit either
  * way.  DEFAULT (neither flag, since ABI 5): a static rule on the launch's size -- XCD-aware when the launch reads at least
  * OFMK_XCD_TILES_MIN_BYTES of frames (192 frames of 1080p), linear below -- which is what interleaved A/B runs on MI355X say
- * (large launches: XCD-aware wins by 1.5-3.4 % or ties; 48-96 frames of 1080p: linear wins by 1-4 %; profiles/r4_mark_fused_pass.txt).
- * The two flags force an order (a caller that has measured its own box: offmark/engine.py calibrate_tile_order); both at once
- * are rejected.  ABI 4 defaulted to the XCD-aware order at every size.  The read-only and one-pass kernels always run in linear
+ * (large launches: XCD-aware wins by 1.5-6 % or ties, depending on where the driver placed the caller's frames; 48-96 frames of
+ * 1080p: linear wins by 1-4 %; profiles/r4_mark_fused_pass.txt, profiles/r6_mark_ladder.txt).
+ * The two flags force an order (a caller that has measured its own box); both at once are rejected.  ABI 4 defaulted to the XCD-aware order at every size.  The read-only and one-pass kernels always run in linear
  * order (measured faster there).  The reference has no counterpart: its loop is one frame at a time
  * (src/offmark/video/embedder.py:18-31). */
 #define OFMK_F_LINEAR_TILES 2u
@@ -76,7 +76,7 @@ typedef struct ofmk_opts {
  * tile, so the launch clears nothing first (no fill dispatch, no global atomics) and the buffer may hold anything before the
  * call.  ofmk_payloads_from_partial_counts adds the tiles up and runs DeShuffler.degenerate's epilogue
  * (de_shuffler.py:17-22; dwt_dct_svd_decoder.py:12-37 produced the bits).  L <= 2048 (else OFMK_E_ARG: use plain counts);
- * any other entry point rejects the flag's meaning by ignoring it. */
+ * every other entry point ignores the flag. */
 #define OFMK_F_PARTIAL_COUNTS 8u
 /* Bytes of device scratch needed to process `frames_in_flight` frames per internal chunk.
  * Any workspace >= ofmk_workspace_bytes(1, H, W) is accepted; the engine sizes its chunks to
