@@ -47,15 +47,24 @@ packets).  `mark_order` times the same K steps with the fused mark kernel in bot
 process, next to the policy the timed region ran under (default: the library's static rule on the launch size; no
 measurement) and the workgroup -> XCD deal the hardware reported.  `embed_only` / `detect_only`: the two operations
 tests/mark.py and tests/detect.py perform, 20 steps each after the timed region (6 and 3 B/px algorithmic).
-At N > 1 only `value` and `second_pass` are measured unless --side-measurements is given; an exception on any rank ends the
-whole job with a non-zero exit and no line (never a rank left behind in a barrier), and every rank binds itself to the cores of
-its GPU's NUMA node before anything touches the GPU (`placement`).
+`value` is timed after a bounded, reported pre-heat (`config.preheat_ms` of untimed steps: device out of idle); `value_no_preheat` is
+the contract read literally -- W warm-up steps from an idle device, then K timed steps -- taken before the pre-heat.
+`kernels` has every kernel kind's launch duration with achieved GB/s and fraction of peak, including `mark`, the NON-fused mark
+kernel tests/mark.py's operation runs.  `oracle_check`: three frames of the timed batch and what the timed steps wrote for them,
+against the C oracle's embed + detect (beside the CPU baseline); an overrun of the parity budgets turns payload_bit_exact false.
+At N > 1 only `value`, `value_no_preheat` and `second_pass` are measured unless --side-measurements is given, and the line gains
+`per_rank` (every rank's own ms per step, dominant-kernel and analyze durations: one all-gather of three floats) and
+`scaling_efficiency_inputs` (slowest / median / fastest rank); both launch paths give the ranks the same environment
+(`collective.env`: rank_environment); an exception on any rank ends the whole job with a non-zero exit and no line (never a rank
+left behind in a barrier); a rank without a shard (--segments fewer than the ranks) still joins every collective; and every rank
+binds itself to the cores of its GPU's NUMA node before anything touches the GPU (`placement`).
 `roofline.traffic` (PMC-measured HBM bytes per launch) is taken from
 profiles/ only when that profile was made from exactly the kernel sources that are running (hash stamp),
 else null.  `cpu_baseline` is the plain-C restatement of the reference algorithm (oracle/offmark_oracle.c,
 bit-identical to the NumPy oracle and the golden vectors; kind "port": OpenCV is not installed, so the
 reference itself cannot run, and OpenCV's own float rounding is parity-unpinned) with one OpenMP thread per
-frame on the host cores this process may use; `cpu_baseline.variants` adds BASELINE.md's A / B1 / B2 forms.
+frame on the host cores this process may use; `cpu_baseline.variants` adds BASELINE.md's A / B1 / B2 forms (A: ten whole frames
+through the reference-shaped per-block loops, one single-threaded worker process per frame).
 """
 import argparse
 import hashlib

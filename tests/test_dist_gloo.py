@@ -312,3 +312,35 @@ def test_both_launch_paths_give_the_ranks_the_same_environment(monkeypatch):
     src = inspect.getsource(bench.main)
     assert 0 < src.index("rank_environment(os.environ, env_world)") < src.index("import torch")
     assert src.index("launch_ranks(a)") < src.index("rank_environment(os.environ, env_world)")
+
+
+def test_bench_oracle_check_bookkeeping_and_budgets():
+    """bench.py's `oracle_check` (dct_decoder.py:10-27): host logic only -- with the C oracle standing in for the
+    GPU on both sides the check must come out clean, and a marked frame that is off by more than one LSB inside a sign-determined
+    block, a flipped raw bit beyond the budget or a wrong payload must each turn `within_budget` false."""
+    import c_oracle
+    import offmark_oracle as orc
+    bench = _load_bench()
+    P8 = np.array([0, 1, 1, 0, 0, 1, 0, 1])
+    H, W = 64, 96
+    frames = np.stack([orc.synthetic_frame(H, W, 40 + i) for i in range(3)])
+    wm = orc.shuffle_generate(P8, (1, H * W // 64), 0)[0].astype(np.uint8)
+    marked = c_oracle.mark_frames(frames, wm, alpha=20, legacy=True, threads=1)[0]
+    bits_of = lambda ref: c_oracle.check_frames(ref, alpha=20, legacy=True, threads=1)[0]      # noqa: E731
+    pay = np.stack([P8] * 3)
+    ok = bench.oracle_check(frames, marked, bits_of, [wm] * 3, 20.0, pay)
+    assert ok["within_budget"] and ok["payload_equal"] and ok["frames"] == 3 and ok["raw_bits_differing"] == 0
+    assert ok["pixels_differing_over_determined_blocks"] == 0 and ok["pixels_compared"] > 0 and ok["blocks"] == 3 * 96
+    # a marked sample three levels off inside a sign-determined block
+    enc = orc.DctEncoderOracle(alpha=20)
+    enc.read_wm(wm[None])
+    enc.encode(orc.bgr2yuv_f32(frames[0].astype(np.float32)))
+    bi, bj = np.argwhere(np.abs(enc.debug["c21_pre"]) > 1e-3)[0]
+    bad = marked.copy()
+    bad[0, bi * 8, bj * 8, 1] = np.clip(int(bad[0, bi * 8, bj * 8, 1]) + 3, 0, 255) if bad[0, bi * 8, bj * 8, 1] < 250 else bad[0, bi * 8, bj * 8, 1] - 3
+    off = bench.oracle_check(frames, bad, bits_of, [wm] * 3, 20.0, pay)
+    assert not off["within_budget"] and off["max_pixel_difference"] == 3 and off["pixels_differing_over_determined_blocks"] == 1
+    # raw bits beyond the budget (floor: one block), and a wrong payload
+    flipped = lambda ref: 1 - bits_of(ref)                                                     # noqa: E731
+    assert not bench.oracle_check(frames, marked, flipped, [wm] * 3, 20.0, pay)["within_budget"]
+    assert not bench.oracle_check(frames, marked, bits_of, [wm] * 3, 20.0, 1 - pay)["within_budget"]
