@@ -942,15 +942,15 @@ def main():
                                    note="the contract read literally: W warm-up steps from an idle device, then K timed steps, BEFORE the pre-heat; "
                                         "`value` is the same K steps after config.preheat_ms of untimed load (device at its operating state)")
     # a few frames of the timed batch and what the timed steps wrote for them, kept for the oracle check beside the CPU baseline
-    # (the side measurements below reuse the output buffer)
+    # (the side measurements below reuse the output buffer).  Device-side copies only: a download here would idle the device for
+    # milliseconds right in front of the second pass, and every idle gap of >= 5 ms is followed by ~15 ms of slower launches
     snap = None
     if a.codec == "dct" and mode == "embed_detect" and not planar and n and rank == 0 and not a.no_cpu_baseline and not emu:
         lane_last, _ = runner.last
         idx = sorted({0, n // 2, n - 1})
         sel = torch.as_tensor(idx, device=dev)
-        rows_sel = job.rows_dev[sel].cpu().numpy() if job.rows_dev is not None else np.zeros(len(idx), np.int64)
-        snap = dict(idx=idx, frames=job.frames[sel].cpu().numpy(), marked=lane_last.out[sel].cpu().numpy(),
-                    wm=[job.wm_table[int(r)] for r in rows_sel], payloads=got_mine[idx])
+        snap = dict(idx=idx, frames=job.frames[sel], marked=lane_last.out[sel], rows=job.rows_dev[sel] if job.rows_dev is not None else None,
+                    payloads=got_mine[idx])
     # Side measurements.  One GPU: each is guarded, a failure is reported inside the line.  N > 1: off unless --side-measurements
     # (every one of them is paid N-fold under barriers), and NEVER guarded: a rank that swallowed an exception would fall out of
     # step with the others' collectives and leave them in a barrier until the driver's time limit -- the exception propagates,
@@ -1378,7 +1378,9 @@ def main():
 
                 def gpu_bits(ref_marked):
                     return e0.detect(torch.from_numpy(ref_marked).to(dev), L, alpha=a.alpha, want_bits=True)[1].cpu().numpy()
-                line["oracle_check"] = oracle_check(snap["frames"], snap["marked"], gpu_bits, snap["wm"], a.alpha, snap["payloads"])
+                rows_sel = snap["rows"].cpu().numpy() if snap["rows"] is not None else np.zeros(len(snap["idx"]), np.int64)
+                line["oracle_check"] = oracle_check(snap["frames"].cpu().numpy(), snap["marked"].cpu().numpy(), gpu_bits,
+                                                    [job.wm_table[int(r)] for r in rows_sel], a.alpha, snap["payloads"])
                 line["oracle_check"]["frame_indices"] = snap["idx"]
                 if not line["oracle_check"]["within_budget"]:
                     line["payload_bit_exact"] = False
