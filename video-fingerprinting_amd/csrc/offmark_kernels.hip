@@ -90,11 +90,10 @@ Ctx make_ctx(void *stream, const ofmk_opts *o) {
 
 // Tile order of one launch of the frame-writing DCT kernel (include/offmark_hip.h: OFMK_F_LINEAR_TILES / OFMK_F_XCD_TILES).
 // Without a flag the library decides by a STATIC rule on the bytes of frames the launch reads: XCD-aware from
-// OFMK_XCD_TILES_MIN_BYTES (192 frames of 1080p) up, linear below.  That is what four rounds of interleaved A/B say
-// (profiles/r4_mark_fused_pass.txt, r4_bench_config4.json, r4_emulate8_config4.json): at 300-384 x 1080p per launch the
-// XCD-aware order wins by 1.5-3.4 % (ties on some boxes), at 192 frames the two tie, at 48-96 frames linear wins by 1-4 %.
-// Round 4 measured the choice per process and launch shape instead; that cost every new batch length 0.25-0.8 s for ~1 % of
-// the step, so measuring is now the caller's explicit request (offmark/engine.py: calibrate_tile_order).
+// OFMK_XCD_TILES_MIN_BYTES (192 frames of 1080p) up, linear below.  That is what every interleaved A/B since round 3 says
+// (profiles/r4_mark_fused_pass.txt, r4_bench_config4.json, r6_mark_ladder.txt): at 300-384 x 1080p per launch the XCD-aware order
+// wins by 1.5-7 % or ties, depending on where the driver placed the caller's frames; at 192 frames the two tie; at 48-96 frames
+// linear wins by 1-4 %.  Nothing is measured at run time (rounds 4-5 carried a calibration mode in the Python engine; removed).
 int tile_xcds(const Ctx &cx, size_t frame_bytes_per_launch) {
     if (cx.flags & OFMK_F_LINEAR_TILES) return 0;
     if (cx.flags & OFMK_F_XCD_TILES) return cx.xcds;

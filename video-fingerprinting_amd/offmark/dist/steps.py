@@ -107,7 +107,7 @@ class StepPipeline:
         t.cuda.synchronize()
 
     def prepare(self):
-        """One full step on every engine (allocations, code objects, the engine's tile-order calibration), then the graphs."""
+        """One full step on every engine (allocations, code objects), then the graphs."""
         t = self.torch
         self.warm_download_path()
         for lane in self.lanes:
