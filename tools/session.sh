@@ -16,8 +16,8 @@ run() {   # run <seconds> <name> <command...>: stdout -> $O/${TAG}_<name>.json|l
 B="python bench.py --no-cpu-baseline"
 for step in "$@"; do
   case $step in
-    tests)     AMD_LOG_LEVEL=1 run 1100 tests python -X faulthandler -m pytest tests -m gpu -v -x; tail -5 $O/${TAG}_tests.out; grep -v "^  File\|amdgpu.ids" $O/${TAG}_tests.err | head -20 ;;
-    tests_all) AMD_LOG_LEVEL=1 run 1100 tests python -X faulthandler -m pytest tests -m gpu -v; tail -30 $O/${TAG}_tests.out | grep -v PASSED; grep -v "^  File\|amdgpu.ids" $O/${TAG}_tests.err | head -20 ;;
+    tests)     AMD_LOG_LEVEL=1 run 1100 tests python -X faulthandler -m pytest tests -m gpu -v -x --capture=sys; tail -5 $O/${TAG}_tests.out; grep -v "^  File\|amdgpu.ids" $O/${TAG}_tests.err | head -20 ;;
+    tests_all) AMD_LOG_LEVEL=1 run 1100 tests python -X faulthandler -m pytest tests -m gpu -v --capture=sys; tail -30 $O/${TAG}_tests.out | grep -v PASSED; grep -v "^  File\|amdgpu.ids" $O/${TAG}_tests.err | head -20 ;;
     memset)    run 200 graph_memset_order python tools/graph_memset_order.py; cat $O/${TAG}_graph_memset_order.out ;;
     line)      run 400 bench_line python bench.py ;;
     line20)    run 400 bench_line_steps20_warmup5 python bench.py --steps 20 --warmup 5 ;;
