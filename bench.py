@@ -52,6 +52,8 @@ the contract read literally -- W warm-up steps from an idle device, then K timed
 `kernels` has every kernel kind's launch duration with achieved GB/s and fraction of peak, including `mark`, the NON-fused mark
 kernel tests/mark.py's operation runs.  `oracle_check`: three frames of the timed batch and what the timed steps wrote for them,
 against the C oracle's embed + detect (beside the CPU baseline); an overrun of the parity budgets turns payload_bit_exact false.
+`dwtdctsvd.oracle_check` / `dwtdctsvd_blk8.oracle_check`: the same three frames as the codec tests/mark.py constructs marked
+them in the side measurement, against the NumPy oracle.
 At N > 1 only `value`, `value_no_preheat` and `second_pass` are measured unless --side-measurements is given, and the line gains
 `per_rank` (every rank's own ms per step, dominant-kernel and analyze durations: one all-gather of three floats) and
 `scaling_efficiency_inputs` (slowest / median / fastest rank); both launch paths give the ranks the same environment
@@ -292,6 +294,47 @@ def oracle_check(frames_u8, marked_u8, gpu_bits_of_oracle_marked, wm_rows, alpha
                 note="frames of the timed batch and the marked frames the timed steps wrote, against the C oracle's embed + detect of the same "
                      "frames; raw bits: the GPU detector and the oracle's on the ORACLE's marked frames; budgets: <= 1 LSB on <= 1e-5 of the "
                      "samples over sign-determined blocks, <= 1e-4 of the raw bits, payloads equal")
+
+
+def oracle_check_svd(frames_u8, marked_u8, gpu_bits_of_oracle_marked, wm_rows, payloads_gpu, blk, scale=15.0):
+    """The same check for the DwtDctSvd codec -- what tests/mark.py and tests/detect.py construct
+    (embed/dwt_dct_svd_encoder.py:19-45, extract/dwt_dct_svd_decoder.py:12-37) -- against the NumPy oracle (no C restatement of this
+    codec exists).  Budgets = tests/test_gpu_svd.py's: marked pixels <= 1 LSB on <= 2e-5 of the samples over DETERMINED tiles (a
+    tile is left out when its top singular value lies within 1e-3 of a multiple of the quantisation step, where the floor
+    division flips on the last float bits, or when its two largest singular values coincide to 1e-3, where the rank-1 direction is
+    not defined); raw bits <= 1e-4 of the tiles; payloads equal."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import offmark_oracle as orc
+    k, H, W, _ = frames_u8.shape
+    px = 2 * blk
+    px_bad = px_n = px_max = left_out = bits_bad = tiles = 0
+    payload_equal = True
+    ref_marked = np.empty_like(frames_u8)
+    ref_bits = []
+    for i in range(k):
+        enc = orc.DwtDctSvdEncoderOracle(scales=(0.0, scale, 0.0), blk=blk)
+        enc.read_wm(np.asarray(wm_rows[i]).reshape(1, -1))
+        ref_marked[i] = orc.mark_frame(frames_u8[i], enc)
+        dbg = enc.debug_ch[1]
+        s0, gap = dbg["s0"].astype(np.float64), dbg["gap"]
+        frac = np.mod(s0, scale)
+        ok = (np.minimum(frac, scale - frac) > 1e-3 * np.maximum(1.0, s0 / 100)) & (gap < 1 - 1e-3)
+        left_out += int((~ok).sum())
+        tiles += int(ok.size)
+        mask = np.zeros((H, W), bool)
+        mask[: ok.shape[0] * px, : ok.shape[1] * px] = np.kron(ok, np.ones((px, px), bool))
+        d = np.abs(marked_u8[i].astype(np.int16) - ref_marked[i].astype(np.int16))[mask]
+        px_bad += int((d > 0).sum())
+        px_n += int(d.size)
+        px_max = max(px_max, int(d.max()) if d.size else 0)
+        ref_bits.append(orc.check_frame(ref_marked[i], orc.DwtDctSvdDecoderOracle(scales=(0.0, scale, 0.0), blk=blk)).reshape(-1))
+        payload_equal &= bool(np.array_equal(orc.deshuffle(ref_bits[-1], PAYLOAD.size, 0), payloads_gpu[i]))
+    got = gpu_bits_of_oracle_marked(ref_marked)
+    for i in range(k):
+        bits_bad += int((got[i].reshape(-1) != ref_bits[i]).sum())
+    within = px_max <= 1 and px_bad <= max(1, int(px_n * 2e-5)) and bits_bad <= max(1, int(tiles * 1e-4)) and payload_equal
+    return dict(frames=k, pixels_compared=px_n, pixels_differing_over_determined_tiles=px_bad, max_pixel_difference=px_max,
+                tiles=tiles, tiles_left_out=left_out, raw_bits_differing=bits_bad, payload_equal=payload_equal, within_budget=bool(within))
 
 
 def attack_suite(torch, detect, clean, per_seg, payloads, chosen, fp, vote_segments, deg, n_bits, H, W, codec):
@@ -1145,6 +1188,8 @@ def main():
                 _, c, _ = e0.svd_embed_detect(job.frames, job.wm_dev, L=L, scale=15, wm_row=job.rows_dev, out=lanes[0].out, blk=blk, partial=True)
                 return e0.payloads(c, DctEngine.svd_bits_per_frame(H, W, blk), perm_dev)
             el4, pm = side_rate(svd_step, k4)
+            if snap is not None:                       # the same three frames as the DCT check, as this codec marked them (device-side copy)
+                snap[key] = (lanes[0].out[torch.as_tensor(snap["idx"], device=dev)], pm[snap["idx"]].cpu().numpy(), blk)
             extra[key] = dict(value=round(world * n * k4 / el4, 1), unit="frames/s", steps=k4, ms_per_step=round(1e3 * el4 / k4, 4),
                               payload_ok=bool((pm.cpu().numpy() == PAYLOAD[None]).all()),
                               algorithmic_GBps=round(n * k4 * 6 * H * W / el4 / 1e9, 1),
@@ -1384,6 +1429,14 @@ def main():
                 line["oracle_check"]["frame_indices"] = snap["idx"]
                 if not line["oracle_check"]["within_budget"]:
                     line["payload_bit_exact"] = False
+                for key in ("dwtdctsvd", "dwtdctsvd_blk8"):      # the codec mark.py / detect.py construct: the same frames against the NumPy oracle
+                    if key in snap and key in line:
+                        marked_svd, pay_svd, blk_ = snap[key]
+
+                        def gpu_bits_svd(ref_marked, blk_=blk_):
+                            return e0.svd_detect(torch.from_numpy(ref_marked).to(dev), L, scale=15, blk=blk_, want_bits=True)[1].cpu().numpy()
+                        line[key]["oracle_check"] = oracle_check_svd(snap["frames"].cpu().numpy(), marked_svd.cpu().numpy(), gpu_bits_svd,
+                                                                     [job.wm_table[int(r)] for r in rows_sel], pay_svd, blk_)
             except Exception as exc:
                 line["oracle_check"] = dict(error=repr(exc))
     print(json.dumps(line), flush=True)

@@ -1184,6 +1184,10 @@ def test_bench_line_checks_its_own_timed_frames_against_the_oracle(config, size)
         assert k["launches"] >= 3 and k["avg_launch_ms"] > 0 and 0 < k["frac_of_peak"] < 1 and k["achieved_GBps"] > 0
         a_ = line["cpu_baseline"]["variants"]["A_reference_shaped_loop"]
         assert a_["frames"] == 10 and a_["payload_ok"] and a_["value"] > 0 and a_["cores"] == 1
+        for key in ("dwtdctsvd", "dwtdctsvd_blk8"):      # the codec mark.py / detect.py construct: the same frames against the NumPy oracle
+            so = line[key]["oracle_check"]
+            assert so["within_budget"] and so["payload_equal"] and so["max_pixel_difference"] <= 1 and so["raw_bits_differing"] <= 1, (key, so)
+            assert so["tiles"] > 0 and so["tiles_left_out"] < so["tiles"] // 2
     print("oracle_check:", {k_: v for k_, v in oc.items() if k_ != "note"})
 
 
