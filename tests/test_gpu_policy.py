@@ -162,3 +162,38 @@ def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
     print(f"12 batch lengths: default engine {1e3 * t_default:.1f} ms, forced order {1e3 * t_forced:.1f} ms")
 
 
+
+
+@pytest.mark.parametrize("alpha", [20.0, 3.7, 0.05, 5.0e-4, 2.0e6])
+def test_fast_readout_equals_float64_for_every_block(eng, alpha):
+    """The detect hot path reads a block's bit from a float32 estimate of C21 / (alpha * tex * lum) wherever that estimate is
+    provably on the same side of every rounding boundary as the float64 quotient, and from the float64 chain elsewhere
+    (csrc/readout.hiph).  Independent check, every block of full frames: the debug-plane kernel (float64 throughout) gives each
+    block's C21 and step; the reference's read-out on those, in float64 on the host (dct_decoder.py:24: around(c21/step) % 2 == 1),
+    must give the detect path's bit for ALL blocks -- no budget.  alpha = 0.05 makes |x| ~ 10^2..10^3, so that thousands of
+    blocks fall inside the guard band and take the exact path; 5e-4 and 2e6 are outside the fast path's alpha range altogether."""
+    import torch
+    from conftest import natural_frame
+    from offmark.synthetic import synthetic_frames
+    H, W = 1080, 1920
+    N = H * W // 64
+    frames = synthetic_frames(4, H, W, seed=2000)                        # brightness offsets cycle: dark / bright / ramp branches
+    rng = np.random.default_rng(77)
+    extreme = np.stack([rng.integers(lo, hi + 1, size=(H, W, 3), dtype=np.uint8) for lo, hi in
+                        ((0, 12), (16, 30), (250, 255), (255, 255), (84, 96))])      # m < 15 / m < 25 branches, mean -> 255 (the
+    frames = torch.cat([frames, cuda(natural_frame()[None]), cuda(extreme)])         # span's reciprocal explodes), saturated white, mean at the 90 clamp
+    wm = orc.shuffle_generate(P8, (1, N), 0)
+    marked = eng.embed(frames, wm, alpha=20.0)                           # lattice points for alpha = 20: exact ties for that alpha's read-out
+    both = torch.cat([frames, marked])
+    counts, bits = eng.detect(both, 8, alpha=alpha, want_bits=True)
+    bits = bits.cpu().numpy()
+    counts = counts.cpu().numpy()
+    total_in_band = 0
+    for i in range(both.shape[0]):
+        planes = eng.debug_planes(both[i], alpha=alpha)
+        x = planes["c21_pre"].astype(np.float64).reshape(-1) / planes["step"].reshape(-1)
+        want = (np.around(x) % 2 == 1).astype(np.uint8)
+        assert np.array_equal(bits[i], want), (alpha, i, int((bits[i] != want).sum()))
+        assert np.array_equal(counts[i], want.reshape(-1, 8).sum(axis=0))
+        total_in_band += int((0.5 - np.abs(x - np.around(x)) <= 4e-6 * (np.abs(x) + 1)).sum())
+    print(f"alpha {alpha}: {total_in_band} of {both.shape[0] * N} blocks inside the guard band (float64 path)")
