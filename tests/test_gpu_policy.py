@@ -162,8 +162,6 @@ def test_default_engine_measures_nothing_over_many_batch_lengths(eng):
     print(f"12 batch lengths: default engine {1e3 * t_default:.1f} ms, forced order {1e3 * t_forced:.1f} ms")
 
 
-
-
 @pytest.mark.parametrize("alpha", [20.0, 3.7, 0.05, 5.0e-4, 2.0e6])
 def test_fast_readout_equals_float64_for_every_block(eng, alpha):
     """The detect hot path reads a block's bit from a float32 estimate of C21 / (alpha * tex * lum) wherever that estimate is
