@@ -471,6 +471,19 @@ def test_tile_orders_are_bit_identical_and_the_xcc_probe_reads_the_deal(eng):
                                ws.data_ptr(), ws.numel(), _hip.current_stream(), both) == -1
     with pytest.raises(ValueError, match="tile_order"):
         type(eng)(tile_order="calibrate")                             # rounds 4-5's opt-in measuring mode is gone
+    # round 6: in XCD order the NON-fused mark kernel is the HOLD form (the 8 marked rows stored at the end, dct_kernels.hiph:
+    # mark_rows) -- also for widths that are no multiple of 8 (byte-wise loads and stores), ragged last tiles, one-tile frames and
+    # in place: same bytes as the row-by-row form in linear order
+    for (h, w, m) in [(64, 100, 9), (30, 44, 5), (17, 9, 3), (8, 8, 70), (360, 652, 11)]:
+        fr = synthetic_frames(m, h, w, seed=500 + w)
+        wmq = np.stack([orc.shuffle_generate(P8, (h * w // 64,), 0), orc.shuffle_generate(1 - P8, (h * w // 64,), 0)])
+        rq = (np.arange(m) % 2).astype(np.int32)
+        lin = type(eng)(tile_order="linear").embed(fr, wmq, wm_row=rq)
+        hold = type(eng)(tile_order="xcd").embed(fr, wmq, wm_row=rq)
+        assert torch.equal(lin, hold), (h, w, m)
+        buf = fr.clone()
+        type(eng)(tile_order="xcd").embed(buf, wmq, wm_row=rq, out=buf)
+        assert torch.equal(buf, lin), (h, w, m)
 
 
 def test_two_threads_two_engines(eng):
