@@ -113,6 +113,9 @@ def parse():
                     help="frame layout in HBM (config 2/3, DCT codec): interleaved rgb24 (the metric) or 4:2:0 planes")
     ap.add_argument("--tile-order", choices=["auto", "xcd", "linear"], default="auto",
                     help="tile order of the frame-writing DCT kernel: auto = the library's static rule on the launch size (default); xcd / linear force one")
+    ap.add_argument("--placement-candidates", type=int, default=8,
+                    help="set-up: the engine's workspace and the output buffer are picked among this many candidate allocations by the real "
+                         "kernels' launch time (offmark/placement.py; reported as config.placement_probe); 0 or 1 = first allocation, no probe")
     ap.add_argument("--segments", type=int, default=8, help="configs 4/5: segments of the job (8 = BASELINE.json's; fewer than the ranks "
                                                             "leaves ranks without a shard: rehearsals and tests)")
     ap.add_argument("--preheat-ms", type=float, default=250.0,
@@ -791,7 +794,32 @@ def main():
             if self.j.n:
                 for e in self.engines():
                     e.workspace(H, W, e._chunk(self.j.n, H, W))
+            self.place()
             super().prepare()
+
+        placement = dict(candidates=1, note="off")
+
+        def place(self):
+            """Where the buffers the kernels WRITE live -- the engine's workspace (the records) and the marked frames' destination --
+            decides which of three speed levels the frame kernels run at; both are this side's to allocate, so they are
+            picked once, at set-up, among a few candidate allocations by the real kernels' launch time over the job's own frames
+            (offmark/placement.py).  Not a workload step; every rank for itself; before any graph is captured."""
+            j = self.j
+            if not (a.placement_candidates > 1 and j.n and not planar and a.codec == "dct" and j.frames.is_contiguous()):
+                return
+            for lane in self.lanes:
+                for eng_name, out_name in (("eng", "out"), ("eng2", "out2")):
+                    e = getattr(lane, eng_name)
+                    if e is None:
+                        continue
+                    want_out = j.mode == "embed_detect"
+                    if want_out:
+                        setattr(lane, out_name, None)                      # the buffer make_out() made goes back to the allocator first
+                    out, rep = e.place_buffers(j.frames, want_out=want_out, candidates=a.placement_candidates)
+                    if want_out:
+                        setattr(lane, out_name, out)
+                    if lane is self.lanes[0] and eng_name == "eng":
+                        self.placement = rep
 
         def preheat(self, ms):
             """Bring the device from idle to its operating state before the contract's W warm-up steps: untimed steps of the
@@ -1381,7 +1409,7 @@ def main():
         "config": {"workload": workload + f"{codec_name} {op}+vote (BASELINE.json {what})",
                    "codec": a.codec, "frames_per_gpu": n, "payload_bits": L, "alpha": a.alpha,
                    "chunk_frames": chunk, "chunks_per_step": n_chunks, "steps_per_host_iteration": G, "hipgraph": bool(use_graph),
-                   "preheat_ms": preheat_ms,
+                   "preheat_ms": preheat_ms, "placement_probe": runner.placement,
                    "tile_order": shipped_order if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "tile_order_policy": shipped_info.get("policy") if (a.codec == "dct" and mode == "embed_detect" and not planar) else None,
                    "detect": ("stand-alone kernels" if (a.separate_detect or mode == "detect") else "fused into the mark kernel")

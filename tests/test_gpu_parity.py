@@ -1192,6 +1192,7 @@ def test_bench_line_checks_its_own_timed_frames_against_the_oracle(config, size)
     assert oc["frames"] == len(oc["frame_indices"]) >= 2 and oc["max_pixel_difference"] <= 1 and oc["raw_bits_differing"] <= 1
     assert oc["pixels_compared"] > 0 and oc["pixels_differing_over_determined_blocks"] <= max(1, oc["pixels_compared"] // 100000)
     assert line["value_no_preheat"] > 0 and line["no_preheat"]["votes_ok"] and line["config"]["preheat_ms"] > 0
+    assert line["config"]["placement_probe"]["candidates"] == 8                 # (these shortened batches are below the probe's size floor)
     if config == 2:
         k = line["kernels"]["mark"]
         assert k["launches"] >= 3 and k["avg_launch_ms"] > 0 and 0 < k["frac_of_peak"] < 1 and k["achieved_GBps"] > 0

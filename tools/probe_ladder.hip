@@ -150,6 +150,100 @@ __global__ __launch_bounds__(kThreads, 4) void read_rung_kernel(const uint8_t *_
     if (x == 0x9E3779B9u && (blockIdx.x ^ threadIdx.x) == 0x5bd1e995u) sink[0] = x;
 }
 
+// analyze's ladder: the read pattern + the record stores and the per-tile partial sum (emit_block) + a dependent VALU chain
+// ARUNG 1: read 8 rows, emit a record made of the loaded words (no arithmetic)     ARUNG 2: + FILL fmas per pixel in front of it
+// STORE: 0 no record stores, 1 three SoA planes (shipped layout: 3 x 256 B per wave), 2 one float4 per block (16 B per lane, 1 KiB per wave),
+//        3 AoS of three floats (12 B per lane);  PF: rows in flight ahead (4 = the shipped rolling prefetch, 8 = all rows up front);  SUM: the
+//        per-tile partial sum (DPP wave sums, LDS, barrier, one u64 store per workgroup)
+template <int ARUNG, int FILL, int STORE = 1, int PF = 4, bool SUM = true>
+__global__ __launch_bounds__(kThreads, 4) void analyze_rung_kernel(const uint8_t *__restrict__ in, Geom g, float *__restrict__ rec,
+                                                                    unsigned long long *__restrict__ ysum) {
+    __shared__ long long s_part[kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!xcd_tile(g.xcds, tiles, g.frames, f, bx)) return;
+    const int c = bx * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    const int cc = valid ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < PF; ++r) raw[r] = load_px8<true>(in + off + (size_t)r * pitch);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r + PF < 8) raw[r + PF] = load_px8<true>(in + off + (size_t)(r + PF) * pitch);      // the shipped kernel's rolling prefetch
+        float a[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) a[x] = px_byte(raw[r], 3 * x + (x & 1));
+        if constexpr (ARUNG >= 2) {
+#pragma unroll
+            for (int k = 0; k < FILL; ++k) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) a[x] = fmaf(a[x], 1.0001f, acc[(x + 1) & 7]);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[x] += a[x];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    BlockFeat ft;
+    ft.a00 = (acc[0] + acc[1]) * 0.03125f;
+    ft.tex = acc[2] + acc[3] + acc[4];
+    ft.c21 = acc[5] + acc[6] - acc[7];
+    if constexpr (ARUNG == 3) {            // the record stores issued FIRST, then FILL fmas per pixel of arithmetic that does not feed them, then the sums
+        if (valid) {
+            const size_t o = (size_t)f * g.nblk + c;
+            rec[o] = ft.a00; rec[o + g.plane] = ft.tex; rec[o + 2 * g.plane] = ft.c21;
+        }
+        float t8[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) t8[x] = acc[x];
+#pragma unroll
+        for (int k = 0; k < FILL * 8; ++k) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) t8[x] = fmaf(t8[x], 1.0001f, acc[(x + 1) & 7]);
+        }
+        ft.a00 = (t8[0] + t8[1] + t8[2] + t8[3] + t8[4] + t8[5] + t8[6] + t8[7]) * 1e-30f + ft.a00;
+        const int q = valid ? __float2int_rn(ft.a00 * 524288.0f) : 0;
+        const int lo = wave_sum(q & 0xffff), hi = wave_sum(q >> 16);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (long long)hi * 65536 + lo;
+        __syncthreads();
+        if (threadIdx.x == 0) ysum[(size_t)f * tiles + bx] = (unsigned long long)(s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+        return;
+    }
+    if constexpr (STORE == 1 && SUM) {
+        emit_block(ft, valid, f, c, bx, tiles, g, rec, ysum, s_part);
+    } else {
+        if (valid) {
+            const size_t o = (size_t)f * g.nblk + c;
+            if constexpr (STORE == 1) { rec[o] = ft.a00; rec[o + g.plane] = ft.tex; rec[o + 2 * g.plane] = ft.c21; }
+            if constexpr (STORE == 2) reinterpret_cast<float4 *>(rec)[o] = make_float4(ft.a00, ft.tex, ft.c21, 0.f);
+            if constexpr (STORE == 3) { rec[3 * o] = ft.a00; rec[3 * o + 1] = ft.tex; rec[3 * o + 2] = ft.c21; }
+            if constexpr (STORE == 4) {                        // the same three stores into a 12 KiB window that never leaves L2: is it the HBM write traffic?
+                const size_t w = (size_t)(c & 1023);
+                rec[w] = ft.a00; rec[w + 1024] = ft.tex; rec[w + 2048] = ft.c21;
+            }
+            if constexpr (STORE == 5) {                        // SoA planes, nontemporal stores
+                __builtin_nontemporal_store(ft.a00, rec + o); __builtin_nontemporal_store(ft.tex, rec + o + g.plane);
+                __builtin_nontemporal_store(ft.c21, rec + o + 2 * g.plane);
+            }
+        }
+        if constexpr (SUM) {
+            const int q = valid ? __float2int_rn(ft.a00 * 524288.0f) : 0;
+            const int lo = wave_sum(q & 0xffff), hi = wave_sum(q >> 16);
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (long long)hi * 65536 + lo;
+            __syncthreads();
+            if (threadIdx.x == 0) ysum[(size_t)f * tiles + bx] = (unsigned long long)(s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+        } else if (STORE == 0) {
+            if (ft.a00 == 1.2345f && ft.tex == ft.c21) rec[0] = ft.a00;      // keeps the loads alive
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // top-down rung: the REAL non-fused mark kernel with one thing taken away
 // ------------------------------------------------------------------------------------------
@@ -664,6 +758,21 @@ int main(int argc, char **argv) {
     add("B  bare read pipelined K=4 contiguous", rd, PIPE_B(false, 4, 1));
     add("L0r bare pattern, read only", rd, [&](int xc) { hipLaunchKernelGGL(read_rung_kernel, xcd_grid(nblk, nf, xc), tb, 0, 0, in, geom(xc), sink); });
     add("L0r bare pattern, read only, 3 WG/CU", rd, [&](int xc) { hipLaunchKernelGGL(read_rung_kernel, xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), sink); });
+#define ARUNG(R, F) [&](int xc) { hipLaunchKernelGGL((analyze_rung_kernel<R, F>), xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), ws2.rec, ws2.ysum); }
+    add("LA1 read pattern + records + partial sums", rd, ARUNG(1, 0));
+#define ARUNGX(R, F, ST, PF, SM) [&](int xc) { hipLaunchKernelGGL((analyze_rung_kernel<R, F, ST, PF, SM>), xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), ws2.rec, ws2.ysum); }
+    add("LA1 no record stores, no partial sums", rd, ARUNGX(1, 0, 0, 4, false));
+    add("LA1 no record stores, partial sums", rd, ARUNGX(1, 0, 0, 4, true));
+    add("LA1 SoA records, no partial sums", rd, ARUNGX(1, 0, 1, 4, false));
+    add("LA1 float4 record per block, partial sums", rd, ARUNGX(1, 0, 2, 4, true));
+    add("LA1 AoS 3-float record, partial sums", rd, ARUNGX(1, 0, 3, 4, true));
+    add("LA1 SoA records, all 8 rows up front", rd, ARUNGX(1, 0, 1, 8, true));
+    add("LA1 no stores, no sums, 8 rows up front", rd, ARUNGX(1, 0, 0, 8, false));
+    add("LA1 records into an L2-resident window, sums", rd, ARUNGX(1, 0, 4, 4, true));
+    add("LA1 SoA records, nontemporal stores, sums", rd, ARUNGX(1, 0, 5, 4, true));
+    add("LA3 SoA records stored BEFORE a 10 fma/px chain", rd, ARUNG(3, 10));
+    add("LA2 + 10 fma/px chain (~850 VALU/wave)", rd, ARUNG(2, 10));
+    add("LA2'+ 16 fma/px chain (~1 250 VALU/wave)", rd, ARUNG(2, 16));
     add("A  analyze, shipped (3 WG/CU LDS cap)", rd, [&](int xc) { hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, true>), xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), ws2.rec, ws2.ysum, nullptr, 0); });
 #define PIPE_A(WV, K, CONTIG, LDS) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((analyze_pipe_kernel<WV>), dim3(pipe_grid(nblk, nf, xc, K)), tb, LDS, 0, in, geom(xc), pp, ws2.rec, ws2.ysum); }
     add("PA analyze pipelined K=2 contiguous", rd, PIPE_A(3, 2, 1, 0));

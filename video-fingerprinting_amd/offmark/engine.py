@@ -120,6 +120,15 @@ class DctEngine:
             self._ws = {(H, W): ws}       # keep one size; frame sizes rarely change within a job
         return ws
 
+    def place_buffers(self, frames, want_out: bool = True, candidates: int = 8):
+        """Set-up for a device-resident batch path: pick this engine's workspace -- and, ``want_out``, a destination for the marked
+        frames -- among ``candidates`` allocations by the real kernels' launch time over ``frames`` (offmark/placement.py: the
+        buffers the kernels WRITE decide which of three speed levels they run at on MI355X, 3-10 % apart; a buffer keeps its level
+        while it lives).  Returns (out tensor or None, report).  Synchronises; call once, before capturing graphs; results never
+        depend on it."""
+        from .placement import place_buffers
+        return place_buffers(self, frames, want_out=want_out, candidates=candidates)
+
     def _chunk(self, n, H, W, bytes_per_sample=1):
         """Frames per internal chunk: equal chunks under the cap (chunk_frames or the byte budget)."""
         return balanced_chunk(n, self.chunk_frames or default_chunk_frames(H, W, bytes_per_sample))
