@@ -342,6 +342,99 @@ __global__ void lum_kernel(const unsigned long long *__restrict__ ysum, int tile
 }
 
 // ------------------------------------------------------------------------------------------
+// candidate 3: a ONE-PLANE hand-over.  analyze stores the texture code only (4 instead of 12 B per block: two thirds of the record write-back gone);
+// the mark kernel recomputes A00 and C21 of the input block from the pixels it holds, in a pre-pass with analyze's own operations (same adds in the
+// same order: bit-identical), before it can form the block's delta.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dc8(const float (&x)[8]) {     // output 0 of dct8s: ((x0+x7)+(x3+x4)) + ((x1+x6)+(x2+x5))
+    return ((x[0] + x[7]) + (x[3] + x[4])) + ((x[1] + x[6]) + (x[2] + x[5]));
+}
+template <bool FUSED, bool HOLD>
+__global__ __launch_bounds__(kThreads, FUSED ? OFMK_FUSED_WAVES : 4) void mark_prepass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, Geom g,
+                                                                                               MarkArgs m, float *rec_out, unsigned long long *__restrict__ ysum_out) {
+    __shared__ FrameLum s_lum;
+    __shared__ long long s_part[kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!xcd_tile(g.xcds, tiles, g.frames, f, bx)) return;
+    const int c = bx * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    const int cc = valid ? c : g.nblk - 1;
+    int bi, bj;
+    divmod_small(cc, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = load_px8<true>(in + off + (size_t)r * pitch);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) forget(raw[r]);
+    frame_lum_to_lds(m.ysum, f, tiles, g.nblk, &s_lum);
+    __syncthreads();
+    if (!FUSED && !valid) return;
+    const float tcode = m.rec[(size_t)f * g.nblk + cc + g.plane];             // the one plane analyze still hands over
+    const int bit = m.wm[(size_t)wm_row_of(m.wm_row, f, m.n_wm) * m.N + cc];
+    float u1[4], dcr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float y[8], u[8];
+        row_yu(raw[r], y, u);
+        fold_u1(u1, r, proj1(u));
+        dcr[r] = dc8(y);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const float a00 = dc8(dcr) * 0.125f;
+    const float c21 = fmaf(u1[1] - u1[2], H6, (u1[0] - u1[3]) * H2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) forget(raw[r]);                                   // the main pass recomputes from the bytes (no 128 floats kept alive)
+    const float d = mark_delta(a00, tcode, c21, s_lum, m.alpha, bit);
+    float R[8][8], u2[4];
+    mark_rows<true, FUSED, HOLD>(raw, d, valid, out + off, pitch, R, u2);
+    if constexpr (FUSED) {
+        const BlockFeat ft = block_features(R, u2);
+        emit_block(ft, valid, f, c, bx, tiles, g, rec_out, ysum_out, s_part);
+    }
+}
+
+// analyze with the one-plane hand-over: everything as shipped, but only the texture code is stored (and the per-tile partial sum)
+__global__ __launch_bounds__(kThreads, OFMK_ANALYZE_WAVES) void analyze_tcode_kernel(const uint8_t *__restrict__ in, Geom g, float *__restrict__ rec,
+                                                                                     unsigned long long *__restrict__ ysum) {
+    __shared__ long long s_part[kThreads / 64];
+    const int tiles = tiles_of(g.nblk);
+    int f, bx;
+    if (!xcd_tile(0, tiles, g.frames, f, bx)) return;
+    const int c = bx * kThreads + threadIdx.x;
+    const bool valid = c < g.nblk;
+    int bi, bj;
+    divmod_small(valid ? c : g.nblk - 1, g.wb, g.inv_wb, bi, bj);
+    const size_t off = (size_t)f * g.frame_stride + ((size_t)bi * 8 * g.W + (size_t)bj * 8) * 3;
+    const int pitch = g.W * 3;
+    const uint8_t *p = in + off;
+    float R[8][8], u1[4];
+    Px8 raw[8];
+#pragma unroll
+    for (int r = 0; r < OFMK_PREFETCH_ROWS; ++r) raw[r] = load_px8<true>(p + (size_t)r * pitch);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r + OFMK_PREFETCH_ROWS < 8) raw[r + OFMK_PREFETCH_ROWS] = load_px8<true>(p + (size_t)(r + OFMK_PREFETCH_ROWS) * pitch);
+        float y[8], u[8];
+        row_yu(raw[r], y, u);
+        fold_u1(u1, r, proj1(u));
+        dct8s(y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) R[r][k] = y[k];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const BlockFeat ft = block_features(R, u1);
+    if (valid) rec[(size_t)f * g.nblk + c + g.plane] = ft.tex;
+    const int q = valid ? __float2int_rn(ft.a00 * 524288.0f) : 0;
+    const int lo = wave_sum(q & 0xffff), hi = wave_sum(q >> 16);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (long long)hi * 65536 + lo;
+    __syncthreads();
+    if (threadIdx.x == 0) ysum[(size_t)f * tiles + bx] = (unsigned long long)(s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// ------------------------------------------------------------------------------------------
 // candidate: K tiles per workgroup, the NEXT tile's pixels loaded before the current tile is computed and stored
 // ------------------------------------------------------------------------------------------
 struct Pipe { int K; int contig; };
@@ -681,6 +774,7 @@ int main(int argc, char **argv) {
     Workspace ws, ws2;
     if (carve(wsp, ws_bytes, H, W, nf, ws) || carve(wsp2, ws_bytes, H, W, nf, ws2)) { fprintf(stderr, "carve: %s\n", g_err); return 2; }
     FrameLum *lum; CK(hipMalloc(&lum, sizeof(FrameLum) * nf));
+    float *ws3rec; CK(hipMalloc(&ws3rec, ws.plane * kRec * sizeof(float)));
     unsigned long long *acc; CK(hipMalloc(&acc, 8));
     unsigned *sink; CK(hipMalloc(&sink, 16));
     hipLaunchKernelGGL(gen_frames, dim3(8192), dim3(256), 0, 0, in, H, W, nf);
@@ -738,6 +832,8 @@ int main(int argc, char **argv) {
     add("R1 real mark, FrameLum precomputed", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<1, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
     add("R2 real mark, stores at the end", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<2, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
     add("R3 real mark, both", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<3, false, 4>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
+    add("RP real mark, A00 / C21 recomputed (one-plane hand-over), HOLD", rw, [&](int xc) { hipLaunchKernelGGL((mark_prepass_kernel<false, true>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
+    add("FP fused, A00 / C21 recomputed (one-plane hand-over)", rw, [&](int xc) { hipLaunchKernelGGL((mark_prepass_kernel<true, false>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
     add("F  real mark+verify (fused), shipped", rw, [&](int xc) { hipLaunchKernelGGL((mark_rgb8_kernel<true, true>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, ws2.rec, ws2.ysum2); });
     add("F1 fused, FrameLum precomputed", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<1, true, 3>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
     add("F2 fused, stores at the end", rw, [&](int xc) { hipLaunchKernelGGL((mark_var_kernel<2, true, 3>), xcd_grid(nblk, nf, xc), tb, 0, 0, in, out, geom(xc), m, lum, ws2.rec, ws2.ysum2); });
@@ -773,6 +869,7 @@ int main(int argc, char **argv) {
     add("LA3 SoA records stored BEFORE a 10 fma/px chain", rd, ARUNG(3, 10));
     add("LA2 + 10 fma/px chain (~850 VALU/wave)", rd, ARUNG(2, 10));
     add("LA2'+ 16 fma/px chain (~1 250 VALU/wave)", rd, ARUNG(2, 16));
+    add("AT analyze storing the texture code only (3 WG/CU)", rd, [&](int xc) { hipLaunchKernelGGL(analyze_tcode_kernel, xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), ws3rec, ws2.ysum); });
     add("A  analyze, shipped (3 WG/CU LDS cap)", rd, [&](int xc) { hipLaunchKernelGGL((analyze_kernel<SRC_RGB8, true>), xcd_grid(nblk, nf, xc), tb, 48 * 1024, 0, in, geom(xc), ws2.rec, ws2.ysum, nullptr, 0); });
 #define PIPE_A(WV, K, CONTIG, LDS) [&](int xc) { const Pipe pp{K, CONTIG}; hipLaunchKernelGGL((analyze_pipe_kernel<WV>), dim3(pipe_grid(nblk, nf, xc, K)), tb, LDS, 0, in, geom(xc), pp, ws2.rec, ws2.ysum); }
     add("PA analyze pipelined K=2 contiguous", rd, PIPE_A(3, 2, 1, 0));
@@ -814,6 +911,16 @@ int main(int argc, char **argv) {
         for (auto &v : V) {
             const char c0 = v.name[0];
             if (c0 == 'L' || c0 == 'B') continue;
+            if (c0 == 'A' && v.name[1] == 'T') {          // the one-plane analyze: its texture-code plane and partial sums must be the shipped kernel's
+                CK(hipMemset(ws3rec, 0xff, ws.plane * kRec * 4)); CK(hipMemset(ws2.ysum, 0xff, (size_t)nf * ws.tiles * 8));
+                v.launch(xc);
+                CK(hipDeviceSynchronize());
+                const bool ok = cksum(ws3rec + ws.plane, ws.plane * 4) == cksum(ws.rec + ws.plane, ws.plane * 4) &&
+                                cksum(ws2.ysum, (size_t)nf * ws.tiles * 8) == ref_ays;
+                printf("# identical to the shipped kernel's result: %-46s %s\n", (v.name + (xc ? " [xcd]" : " [lin]")).c_str(), ok ? "yes" : "NO");
+                if (!ok) ++bad;
+                continue;
+            }
             if (c0 == 'A' || (c0 == 'P' && v.name[1] == 'A')) {
                 CK(hipMemset(ws2.rec, 0xff, ws.plane * kRec * 4)); CK(hipMemset(ws2.ysum, 0xff, (size_t)nf * ws.tiles * 8));
                 v.launch(xc);
@@ -823,7 +930,7 @@ int main(int argc, char **argv) {
                 if (!ok) ++bad;
                 continue;
             }
-            const bool fused = c0 == 'F' || (c0 == 'P' && v.name[1] == 'F');
+            const bool fused = (c0 == 'F') || (c0 == 'P' && v.name[1] == 'F');
             if (fused) { CK(hipMemset(ws2.rec, 0xff, ws.plane * kRec * 4)); CK(hipMemset(ws2.ysum2, 0xff, (size_t)nf * ws.tiles * 8)); }
             v.launch(xc);
             check((v.name + (xc ? " [xcd]" : " [lin]")).c_str(), fused);
