@@ -25,40 +25,28 @@ DEFAULT_CANDIDATES = 8
 MIN_BYTES = 256 << 20         # batches smaller than this are launch-bound: nothing to gain
 
 
-def _pick(torch, candidates, run, rounds=3, launches=3, preheat_ms=60.0):
-    """Median launch time of run(candidate) per candidate, rounds interleaved in alternating direction after a short pre-heat
-    (a device coming out of idle speeds up for ~100 ms: without it the candidates probed last would win).  -> (best index, ms[])"""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    while 1e3 * (time.perf_counter() - t0) < preheat_ms:
-        for _ in range(8):
-            run(candidates[0])
-        torch.cuda.current_stream().synchronize()
-    ms = np.zeros((rounds, len(candidates)))
-    for r in range(rounds):
-        order = range(len(candidates)) if r % 2 == 0 else range(len(candidates) - 1, -1, -1)
-        for i in order:
-            run(candidates[i])                                   # untimed first touch
-            e0.record()
-            for _ in range(launches):
-                run(candidates[i])
-            e1.record()
-            e1.synchronize()
-            ms[r, i] = e0.elapsed_time(e1) / launches
-    med = np.median(ms, axis=0)
-    return int(np.argmin(med)), med
+def _alloc_spread(make, k, spacer=None):
+    """k candidate allocations, all alive: half of them, a throw-away spacer, then the rest -- consecutive allocations tend to share
+    a level, allocations on either side of a gap tend not to (profiles/r6_placement_ab.txt)."""
+    out = [make() for _ in range((k + 1) // 2)]
+    gap = (spacer or make)()
+    out += [make() for _ in range(k - len(out))]
+    del gap
+    return out
 
 
-def place_buffers(engine, frames, want_out: bool = True, candidates: int = DEFAULT_CANDIDATES, max_bytes: int | None = None):
+def place_buffers(engine, frames, want_out: bool = True, candidates: int = DEFAULT_CANDIDATES, max_bytes: int | None = None, rounds: int = 3):
     """frames: contiguous CUDA uint8 [n, H, W, 3] -- the batch (or one like it, in the same allocation) the engine will work on.
-    Picks the engine's workspace for this frame size among `candidates` allocations by the analyze kernel's time over `frames`,
-    then (want_out) the destination of the marked frames among `candidates` allocations by the fused mark + verify kernel's time;
-    returns (out tensor or None, report).  Synchronises; call once at set-up, before capturing graphs.  `max_bytes`: upper bound
-    on what the output candidates may take together (default: a third of the device's free memory)."""
+    Picks the engine's workspace for this frame size among `candidates` allocations, then (want_out) the destination of the marked
+    frames among `candidates` allocations; returns (out tensor or None, report).  The probe is the real sequence -- analyze, then the
+    fused mark + verify kernel -- launched `rounds` x 3 times per candidate, interleaved in alternating direction, each kernel timed
+    by its own dispatch timestamps: analyze + mark decide the workspace (both touch the records), mark decides the output buffer.
+    (Timing analyze alone, launch after launch, flatters it: the previous launch's records are still in the Infinity Cache.)
+    Synchronises; call once at set-up, before capturing graphs.  `max_bytes`: upper bound on what the output candidates may take
+    together (default: a third of the device's free memory)."""
     t = engine.torch
     n, H, W = engine._check_frames(frames, t.uint8)
     report = dict(candidates=int(candidates))
-    out = None
     if candidates < 2 or frames.numel() < MIN_BYTES:
         report["note"] = "off" if candidates < 2 else "batch too small to matter"
         return (t.empty_like(frames) if want_out else None), report
@@ -66,35 +54,70 @@ def place_buffers(engine, frames, want_out: bool = True, candidates: int = DEFAU
     cf = engine._chunk(n, H, W)
     part = frames[:cf]
     nbytes = lib.ofmk_workspace_bytes(cf, H, W)
-    with t.cuda.device(engine.device):
-        wss = [t.empty(nbytes, dtype=t.uint8, device=engine.device) for _ in range(candidates)]
-
-        def analyze(ws):
-            _hip.check(lib.ofmk_stage_analyze_rgb8(part.data_ptr(), cf, H, W, ws.data_ptr(), ws.numel(), s, None))
-        best, ms = _pick(t, wss, analyze)
-        ws = wss[best]
-        engine._ws = {(H, W): ws}                                 # what engine.workspace(H, W, <= cf) hands out from now on
-        report["workspace"] = dict(chosen=best, analyze_ms=[round(float(x), 4) for x in ms])
-        del wss
-        if want_out:
+    kinds = ("analyze", "mark_fused")
+    pool = _hip.Timing(64, sum(1 << _hip.TIMING_KINDS.index(k) for k in kinds))
+    timed = _hip.opts_ref(_hip.Opts(0, 0, pool.handle))
+    try:
+        with t.cuda.device(engine.device):
             free, _ = t.cuda.mem_get_info(engine.device)
             budget = free // 3 if max_bytes is None else int(max_bytes)
-            k = int(max(1, min(candidates, budget // max(frames.numel(), 1))))
-            outs = [t.empty_like(frames) for _ in range(k)]
+            k_out = int(max(1, min(candidates, budget // max(frames.numel(), 1) - 1))) if want_out else 0
+            outs = _alloc_spread(lambda: t.empty_like(frames), k_out) if k_out > 1 else ([t.empty_like(frames)] if want_out else [])
+            # the workspace is small: twice as many candidates, a 1 GiB gap between the halves
+            wss = _alloc_spread(lambda: t.empty(nbytes, dtype=t.uint8, device=engine.device), 2 * candidates,
+                                spacer=lambda: t.empty(1 << 30, dtype=t.uint8, device=engine.device))
             wm = t.zeros((1, H * W // 64), dtype=t.uint8, device=engine.device)
             wm[0, ::2] = 1
-            analyze(ws)                                          # the records the mark kernel reads
 
-            def mark(o):
-                _hip.check(lib.ofmk_stage_mark_rgb8(part.data_ptr(), o.data_ptr(), cf, H, W, wm.data_ptr(), 20.0, 1, ws.data_ptr(), ws.numel(), s, None))
-            if k > 1:
-                best_o, ms_o = _pick(t, outs, mark, preheat_ms=0.0)
-            else:
-                best_o, ms_o = 0, np.zeros(1)
-            out = outs[best_o]
-            report["output"] = dict(chosen=best_o, fused_mark_ms=[round(float(x), 4) for x in ms_o])
-            del outs
+            def seq(ws, o, opts):
+                _hip.check(lib.ofmk_stage_analyze_rgb8(part.data_ptr(), cf, H, W, ws.data_ptr(), ws.numel(), s, opts))
+                if o is not None:
+                    _hip.check(lib.ofmk_stage_mark_rgb8(part.data_ptr(), o.data_ptr(), cf, H, W, wm.data_ptr(), 20.0, 1, ws.data_ptr(), ws.numel(), s, opts))
+
+            def score(ws, o, launches=3):
+                seq(ws, o, None)                                 # untimed first touch
+                for _ in range(launches):
+                    seq(ws, o, timed)
+                t.cuda.current_stream().synchronize()
+                got = pool.collect()
+                return [got[k]["ms_total"] / max(got[k]["launches"], 1) for k in kinds]
+
+            o0 = outs[0] if outs else None
+            t0 = time.perf_counter()                             # a device coming out of idle speeds up for ~100 ms: without this the
+            while 1e3 * (time.perf_counter() - t0) < 60.0:      # candidates probed last would win
+                for _ in range(6):
+                    seq(wss[0], o0, None)
+                t.cuda.current_stream().synchronize()
+
+            def sweep(items, run):
+                ms = np.zeros((rounds, len(items), 2))
+                for r in range(rounds):
+                    order = range(len(items)) if r % 2 == 0 else range(len(items) - 1, -1, -1)
+                    for i in order:
+                        ms[r, i] = run(items[i])
+                return np.median(ms, axis=0)
+
+            med = sweep(wss, lambda w: score(w, o0))
+            best = int(np.argmin(med.sum(axis=1)))
+            ws = wss[best]
+            engine._ws = {(H, W): ws}                             # what engine.workspace(H, W, <= cf) hands out from now on
+            report["workspace"] = dict(chosen=best, analyze_ms=[round(float(x), 4) for x in med[:, 0]],
+                                       fused_mark_ms=[round(float(x), 4) for x in med[:, 1]] if o0 is not None else None)
+            del wss
+            out = None
+            if want_out:
+                if len(outs) > 1:
+                    med_o = sweep(outs, lambda o: score(ws, o))
+                    best_o = int(np.argmin(med_o[:, 1]))
+                    report["output"] = dict(chosen=best_o, fused_mark_ms=[round(float(x), 4) for x in med_o[:, 1]])
+                else:
+                    best_o = 0
+                    report["output"] = dict(chosen=0, fused_mark_ms=[], note="no room for a second candidate")
+                out = outs[best_o]
+            del outs, o0
+    finally:
+        pool.close()
     t.cuda.current_stream().synchronize()
-    report["note"] = ("engine-owned buffers picked among candidate allocations by the real kernels' launch time over the caller's frames "
-                      "(median of 3 interleaved rounds of 3 launches); the losers go back to the allocator")
+    report["note"] = ("engine-owned buffers picked among candidate allocations by the real kernels' launch time over the caller's frames (analyze, then "
+                      f"the fused mark kernel; median of {rounds} interleaved rounds of 3 launches, dispatch timestamps); the losers go back to the allocator")
     return out, report
