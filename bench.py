@@ -47,6 +47,9 @@ packets).  `mark_order` times the same K steps with the fused mark kernel in bot
 process, next to the policy the timed region ran under (default: the library's static rule on the launch size; no
 measurement) and the workgroup -> XCD deal the hardware reported.  `embed_only` / `detect_only`: the two operations
 tests/mark.py and tests/detect.py perform, 20 steps each after the timed region (6 and 3 B/px algorithmic).
+Set-up also places the two buffers the kernels WRITE -- the engine's workspace and the marked frames' destination -- among candidate
+allocations by the real kernels' launch time over the job's frames (offmark/placement.py; `config.placement_probe`; --placement-candidates 1
+turns it off): on MI355X their physical backing decides which of three speed levels the frame kernels run at.
 `value` is timed after a bounded, reported pre-heat (`config.preheat_ms` of untimed steps: device out of idle); `value_no_preheat` is
 the contract read literally -- W warm-up steps from an idle device, then K timed steps -- taken before the pre-heat.
 `kernels` has every kernel kind's launch duration with achieved GB/s and fraction of peak, including `mark`, the NON-fused mark
