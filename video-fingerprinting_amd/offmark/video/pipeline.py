@@ -87,7 +87,16 @@ class HostRegistration:
 
     def close(self):
         if self._ptr is not None and self.array.nbytes:
-            self._rt.cudaHostUnregister(self._ptr)
+            # no copy engine may still be reading or writing these pages when they stop being page-locked (the pipeline has synchronised its
+            # streams by now; a caller that used the array for copies of its own may not have), and a failed unregistration must not pass in
+            # silence: the range would stay registered while its memory goes back to the allocator
+            import torch
+            if torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+            rc = int(self._rt.cudaHostUnregister(self._ptr))
+            if rc != 0:
+                import logging
+                logging.getLogger(__name__).warning("hipHostUnregister failed with code %d for %d bytes at %#x", rc, self.array.nbytes, self._ptr)
         self._ptr = None
 
     def __del__(self):
