@@ -43,7 +43,7 @@ def place_buffers(engine, frames, want_out: bool = True, candidates: int = DEFAU
     by its own dispatch timestamps: analyze + mark decide the workspace (both touch the records), mark decides the output buffer.
     (Timing analyze alone, launch after launch, flatters it: the previous launch's records are still in the Infinity Cache.)
     Synchronises; call once at set-up, before capturing graphs.  `max_bytes`: upper bound on what the output candidates may take
-    together (default: a third of the device's free memory)."""
+    together (default: 55 % of the device's free memory)."""
     t = engine.torch
     n, H, W = engine._check_frames(frames, t.uint8)
     report = dict(candidates=int(candidates))
@@ -60,7 +60,7 @@ def place_buffers(engine, frames, want_out: bool = True, candidates: int = DEFAU
     try:
         with t.cuda.device(engine.device):
             free, _ = t.cuda.mem_get_info(engine.device)
-            budget = free // 3 if max_bytes is None else int(max_bytes)
+            budget = int(free * 0.55) if max_bytes is None else int(max_bytes)
             k_out = int(max(1, min(candidates, budget // max(frames.numel(), 1) - 1))) if want_out else 0
             outs = _alloc_spread(lambda: t.empty_like(frames), k_out) if k_out > 1 else ([t.empty_like(frames)] if want_out else [])
             # the workspace is small: twice as many candidates, a 1 GiB gap between the halves
